@@ -1,0 +1,237 @@
+"""ctypes binding of include/bnr_hip.h (libbnr_hip.so).  No torch types cross this boundary.
+
+The HIP library is the ONLY compute path of the package: if the shared object is missing or a call fails the
+error is raised, never papered over with a CPU fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._build import LIB
+
+BNR_OK = 0
+ERRORS = {1: "bad argument", 2: "HIP error", 3: "Cholesky failed after jitter", 4: "sampler attempt cap"}
+
+
+class BnrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libbnr_hip: %s (status %d: %s)" % (msg, code, ERRORS.get(code, "?")))
+        self.code = code
+
+
+class Hyper(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("eta", "zeta", "iota", "aDelta", "bDelta", "nu")]
+
+
+PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int64)
+_dp = C.c_void_p
+_lib = None
+
+_SIGS = {
+    "bnr_abi_version": (C.c_int, []),
+    "bnr_last_error": (C.c_char_p, []),
+    "bnr_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "bnr_chain_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(Hyper), C.c_uint64, C.c_int32,
+                                   C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "bnr_chain_destroy": (C.c_int, [C.c_void_p]),
+    "bnr_chain_init_prior": (C.c_int, [C.c_void_p]),
+    "bnr_chain_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, PROGRESS_CB, C.c_void_p,
+                                C.POINTER(C.c_int32)]),
+    "bnr_chain_run_async": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "bnr_chain_sync": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "bnr_gibbs_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
+    "bnr_chain_get_iter": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "bnr_chain_set_iter": (C.c_int, [C.c_void_p, C.c_int64]),
+    "bnr_chain_fetch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [_dp] * 11),
+    "bnr_chain_load": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [_dp] * 11),
+    "bnr_chain_move_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "bnr_chain_resize": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bnr_chain_rhat_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
+    "bnr_rhat_from_stats": (C.c_int, [_dp, C.c_int32, C.c_int32, C.c_int32, _dp]),
+    "bnr_chain_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "bnr_chain_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bnr_chain_last_timing": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "bnr_chain_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "bnr_host_philox": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "bnr_host_uniform2": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+    "bnr_host_normal": (C.c_double, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "bnr_host_gamma": (C.c_double, [C.c_uint64, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "bnr_host_gig": (C.c_double, [C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32]),
+    "bnr_host_edge_index": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+}
+for _u in ("tau2", "u_xi", "gamma", "D", "theta", "Delta", "M", "mu", "Lambda", "pi"):
+    _SIGS["bnr_update_" + _u] = (C.c_int, [C.c_void_p, C.c_int32, C.c_int64])
+
+EXPORTS = sorted(_SIGS)
+
+
+def lib():
+    """Load libbnr_hip.so; raises if it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise ImportError("libbnr_hip.so is missing at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB)
+        L = C.CDLL(LIB)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != BNR_OK:
+        raise BnrError(code, lib().bnr_last_error().decode())
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+TABLE_COLUMNS = ["tau2", "u", "xi", "gamma", "S", "theta", "Delta", "M", "mu", "lam", "pi"]
+DEAD_COLUMNS = ["Sigma_inv", "invC", "mu_t"]   # allocated, never written by the reference (gibbs.jl:840-841)
+
+
+def table_shapes(V, R):
+    q = V * (V + 1) // 2
+    return dict(tau2=(1, 1), u=(R, V), xi=(V, 1), gamma=(q, 1), S=(q, 1), theta=(1, 1), Delta=(1, 1), M=(R, R),
+                mu=(1, 1), lam=(R, 1), pi=(R, 3), Sigma_inv=(R, R), invC=(R, R), mu_t=(R, 1))
+
+
+def new_table(tot, V, R, dead=True):
+    """The reference's state Table: every column Array{Float64,3}(tot,d1,d2), iteration index fastest."""
+    names = TABLE_COLUMNS + (DEAD_COLUMNS if dead else [])
+    sh = table_shapes(V, R)
+    return {k: np.zeros((tot,) + sh[k], dtype=np.float64, order="F") for k in names}
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().bnr_device_count(C.byref(n)))
+    return n.value
+
+
+class Chain:
+    """One Gibbs chain resident on one GPU (handle of include/bnr_hip.h)."""
+
+    def __init__(self, X, y, R, tot_save, seed, chain_id, device=0, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0,
+                 bDelta=1.0, nu=10):
+        Xf = np.asfortranarray(X, dtype=np.float64)
+        yf = np.ascontiguousarray(y, dtype=np.float64)
+        n, q = Xf.shape
+        V = int(round((-1 + np.sqrt(1 + 8 * q)) / 2))
+        if V * (V + 1) // 2 != q:
+            raise ValueError("X must have V(V+1)/2 columns")
+        if yf.shape != (n,):
+            raise ValueError("y must have one entry per row of X")
+        self.n, self.q, self.V, self.R, self.tot = n, q, V, int(R), int(tot_save)
+        self.h = C.c_void_p()
+        hy = Hyper(eta, zeta, iota, aDelta, bDelta, float(nu))
+        self.L = lib()
+        check(self.L.bnr_chain_create(n, V, int(R), _ptr(Xf), _ptr(yf), C.byref(hy), C.c_uint64(int(seed) & (2**64 - 1)),
+                                      int(chain_id), int(device), int(tot_save), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.bnr_chain_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def init_prior(self):
+        check(self.L.bnr_chain_init_prior(self.h))
+
+    def run(self, first_index, nburn, total, purge_burn=None, prog_freq=0, callback=None):
+        nxt = C.c_int32(0)
+        cb = PROGRESS_CB(lambda user, done: callback(done)) if callback else PROGRESS_CB()
+        check(self.L.bnr_chain_run(self.h, first_index, nburn, total, purge_burn or 0, prog_freq if callback else 0, cb,
+                                   None, C.byref(nxt)))
+        return nxt.value
+
+    def run_async(self, first_index, nburn, total, purge_burn=None):
+        check(self.L.bnr_chain_run_async(self.h, first_index, nburn, total, purge_burn or 0))
+
+    def sync(self):
+        nxt = C.c_int32(0)
+        check(self.L.bnr_chain_sync(self.h, C.byref(nxt)))
+        return nxt.value
+
+    def gibbs_step(self, row, it):
+        check(self.L.bnr_gibbs_step(self.h, row, it))
+
+    def update(self, name, row, it):
+        check(getattr(self.L, "bnr_update_" + name)(self.h, row, it))
+
+    @property
+    def iter(self):
+        v = C.c_int64(0)
+        check(self.L.bnr_chain_get_iter(self.h, C.byref(v)))
+        return v.value
+
+    @iter.setter
+    def iter(self, v):
+        check(self.L.bnr_chain_set_iter(self.h, int(v)))
+
+    def fetch(self, first_row=1, last_row=None, table=None, host_row_offset=0):
+        last_row = self.tot if last_row is None else last_row
+        if table is None:
+            table = new_table(last_row - first_row + 1, self.V, self.R, dead=False)
+            host_row_offset = -(first_row - 1)
+        tot = table["tau2"].shape[0]
+        for k in TABLE_COLUMNS:
+            a = table[k]
+            assert a.dtype == np.float64 and a.flags.f_contiguous and a.shape[0] == tot, k
+        check(self.L.bnr_chain_fetch(self.h, first_row, last_row, tot, host_row_offset, *[_ptr(table[k]) for k in TABLE_COLUMNS]))
+        return table
+
+    def load(self, table, first_row=1, last_row=None, host_row_offset=0):
+        tot = table["tau2"].shape[0]
+        last_row = min(self.tot, tot - host_row_offset) if last_row is None else last_row
+        cols = []
+        for k in TABLE_COLUMNS:
+            a = table.get(k)
+            if a is not None:
+                a = np.asfortranarray(a, dtype=np.float64)
+                assert a.shape[0] == tot, k
+            cols.append(a)
+        self._keep = cols
+        check(self.L.bnr_chain_load(self.h, first_row, last_row, tot, host_row_offset, *[_ptr(a) for a in cols]))
+
+    def move_rows(self, to_row, from_row, count):
+        check(self.L.bnr_chain_move_rows(self.h, to_row, from_row, count))
+
+    def resize(self, new_tot):
+        check(self.L.bnr_chain_resize(self.h, new_tot))
+        self.tot = int(new_tot)
+
+    def rhat_stats(self, first_row, nsamp):
+        out = np.empty(4 * (self.q + self.V))
+        check(self.L.bnr_chain_rhat_stats(self.h, first_row, nsamp, _ptr(out)))
+        return out
+
+    def counters(self):
+        out = (C.c_int64 * 8)()
+        check(self.L.bnr_chain_counters(self.h, out))
+        return dict(jitter=out[0], nan_w=out[1], sampler_cap=out[2], chol_fail=out[3])
+
+    def set_profiling(self, on=True):
+        check(self.L.bnr_chain_set_profiling(self.h, 1 if on else 0))
+
+    def last_timing(self, which):
+        us, n = C.c_double(0), C.c_int64(0)
+        check(self.L.bnr_chain_last_timing(self.h, which, C.byref(us), C.byref(n)))
+        return us.value, n.value
+
+    def set_option(self, name, value):
+        check(self.L.bnr_chain_set_option(self.h, name.encode(), int(value)))
+
+
+def rhat_from_stats(stats, nsamp):
+    """stats: (nchains, 4*nparams) -> rhat (nparams,)   second half of convergence.jl:4-65."""
+    s = np.ascontiguousarray(stats, dtype=np.float64)
+    nchains, w = s.shape
+    out = np.empty(w // 4)
+    check(lib().bnr_rhat_from_stats(_ptr(s), nchains, w // 4, nsamp, _ptr(out)))
+    return out

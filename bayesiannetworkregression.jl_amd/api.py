@@ -1,0 +1,418 @@
+"""Host-side mirror of the reference's public and chain-driver API for the Gibbs hot path, over the C ABI.
+
+Julia is not available in this image, so the thin host layer a Julia user would get from julia/BNRHip.jl
+(ccall) is mirrored here in Python (ctypes) with the reference's names, argument meaning and defaults:
+
+  Fit!                   gibbs.jl:725-751   -> Fit
+  generate_samples!      gibbs.jl:897-1020  -> generate_samples
+  generate_samples_dbl!  gibbs.jl:1051-1198 -> generate_samples_dbl
+  initialize_and_run!    gibbs.jl:822-846   -> initialize_and_run
+  run!                   gibbs.jl:849-864   -> run
+  return_psrf_VOI        gibbs.jl:771-789   -> return_psrf_VOI
+  Results / BNRSummary   gibbs.jl:23-43     -> Results / BNRSummary
+  Summary                gibbs.jl:1214-1250 -> Summary
+  lower_triangle / create_lower_tri / setup_X!  utils.jl:17-57, gibbs.jl:239-247
+
+All sampling runs on the GPU through libbnr_hip.so; this file holds only the schedule logic (chain fan-out,
+PSRF-driven top-ups), the table layout and the post-processing that the reference also does on the host.
+Chains are placed one (or several) per GPU; with torch.distributed initialised, chains are sharded over ranks and
+the per-chain split-Rhat statistics are all-gathered (RCCL on GPUs, gloo on CPU tests).
+"""
+import datetime
+import math
+import random
+import sys
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi
+from ._capi import Chain, new_table, rhat_from_stats
+
+CITATION = ("If you use BayesianNetworkRegression.jl, please cite:\n@article{Ozminkowski2022,\n"
+            "author = {Ozminkowski, S. and Sol\\'{i}s-Lemus, C.},\nyear = {2022},\n"
+            "title = {{Identifying microbial drivers in biological phenotypes with a Bayesian Network Regression model}},\n"
+            "journal = {In preparation}\n}")
+
+
+# ------------------------------------------------------------------------------------------ utils.jl
+def lower_triangle(matrix):
+    """utils.jl:40-57: column-wise lower triangle INCLUDING the diagonal; reads matrix[j,i], j>=i."""
+    m = np.asarray(matrix)
+    if m.shape[0] != m.shape[1]:
+        raise ValueError("matrix must be square")
+    V = m.shape[0]
+    return np.concatenate([m[i:, i] for i in range(V)])
+
+
+def create_lower_tri(vector, V):
+    """utils.jl:17-27: inverse of lower_triangle (upper part zero)."""
+    v = np.asarray(vector).reshape(-1)
+    mat = np.zeros((V, V), dtype=v.dtype)
+    i = 0
+    for k in range(V):
+        mat[k:, k] = v[i:i + V - k]
+        i += V - k
+    return mat
+
+
+def setup_X(X, x_transform=True):
+    """setup_X! (gibbs.jl:239-247) + the V,q bookkeeping of generate_samples! (907-918) -> (X_new n x q float64, V, q)."""
+    if x_transform:
+        V = np.asarray(X[0]).shape[0]
+        q = V * (V + 1) // 2
+        X_new = np.empty((len(X), q), dtype=np.float64, order="F")
+        for i in range(len(X)):
+            X_new[i, :] = lower_triangle(X[i])
+    else:
+        X_new = np.asfortranarray(X, dtype=np.float64)
+        q = X_new.shape[1]
+        V = int((-1 + math.sqrt(1 + 8 * q)) / 2)
+    return X_new, V, q
+
+
+# ------------------------------------------------------------------------------------------ output structs
+@dataclass
+class Results:
+    """gibbs.jl:23-29.  state: dict of arrays (tot_save,d1,d2) in the reference layout (chain 1 only)."""
+    state: dict
+    rhatxi: np.ndarray
+    rhatgamma: np.ndarray
+    burn_in: int
+    sampled: int
+
+
+@dataclass
+class BNRSummary:
+    """gibbs.jl:39-43 (DataFrames replaced by dicts of columns)."""
+    edge_coef: dict
+    prob_nodes: dict
+    ci_level: int
+
+    def __str__(self):
+        e, p = self.edge_coef, self.prob_nodes
+        lines = ["", "Edge Coefficient Estimates (%d%% credible intervals)" % self.ci_level,
+                 " node1 node2 estimate lower_bound upper_bound"]
+        for i in range(len(e["node1"])):
+            lines.append(" %5d %5d %8.3f %11.3f %11.3f" % (e["node1"][i], e["node2"][i], e["estimate"][i], e["lower_bound"][i], e["upper_bound"][i]))
+        lines.append("Node Probabilities")
+        lines += [" %.3f" % v for v in p["probability"]]
+        return "\n".join(lines)
+
+
+def _julia_round(x):
+    """Julia's round(): half to even, like Python's round() on floats."""
+    return int(round(x))
+
+
+def Summary(results, interval=95, digits=3):
+    """gibbs.jl:1214-1250."""
+    nburn, nsamp = results.burn_in, results.sampled
+    total = nburn + nsamp
+    lower_bound = (100 - interval) / 200
+    upper_bound = 1 - lower_bound
+    g = results.state["gamma"][nburn:total, :, 0]
+    g_sorted = np.sort(g, axis=0)
+    lw = _julia_round(nsamp * lower_bound)
+    hi = _julia_round(nsamp * upper_bound)
+    q = g.shape[1]
+    V = int((-1 + math.sqrt(1 + 8 * q)) / 2)
+    node1, node2 = [], []
+    for k in range(1, V + 1):
+        for l in range(k, V + 1):
+            node1.append(k)
+            node2.append(l)
+    edge = dict(node1=np.array(node1), node2=np.array(node2), estimate=np.round(g.mean(axis=0), digits),
+                lower_bound=np.round(g_sorted[lw - 1, :], digits), upper_bound=np.round(g_sorted[hi - 1, :], digits))
+    xi = dict(probability=np.round(results.state["xi"][nburn:total, :, 0].mean(axis=0), digits))
+    return BNRSummary(edge, xi, interval)
+
+
+# ------------------------------------------------------------------------------------------ chain placement
+def _dist():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist
+    except Exception:
+        pass
+    return None
+
+
+def _rank_world():
+    d = _dist()
+    return (d.get_rank(), d.get_world_size()) if d else (0, 1)
+
+
+def local_chain_ids(num_chains):
+    """Chains c = 1..num_chains are sharded round-robin over ranks (the reference's pmap, gibbs.jl:946)."""
+    rank, world = _rank_world()
+    return [c for c in range(1, num_chains + 1) if (c - 1) % world == rank]
+
+
+def _default_device():
+    import os
+    return int(os.environ.get("LOCAL_RANK", "0")) if _dist() else 0
+
+
+def allgather_stats(local_stats, num_chains):
+    """All-gather of the per-chain split-Rhat messages (4*(q+V) doubles each).  local_stats: {chain_id: array}.
+    Returns (num_chains, 4*(q+V)) in chain order on every rank.  With torch.distributed on GPUs this is one RCCL
+    all_gather of a small device tensor per rank; on CPU tests the same code runs over gloo."""
+    d = _dist()
+    width = len(next(iter(local_stats.values()))) if local_stats else 0
+    if d is None:
+        return np.stack([local_stats[c] for c in range(1, num_chains + 1)])
+    import torch
+    rank, world = _rank_world()
+    per_rank = (num_chains + world - 1) // world
+    wt = torch.tensor([width], dtype=torch.int64)
+    use_cuda = d.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+    wt = wt.to(dev)
+    d.all_reduce(wt, op=d.ReduceOp.MAX)
+    width = int(wt.item())
+    buf = torch.zeros(per_rank, width, dtype=torch.float64)
+    for slot, c in enumerate(sorted(local_stats)):
+        buf[slot] = torch.from_numpy(np.asarray(local_stats[c], dtype=np.float64))
+    buf = buf.to(dev)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    d.all_gather(out, buf)
+    allv = torch.stack(out).cpu().numpy()          # (world, per_rank, width)
+    res = np.empty((num_chains, width))
+    for c in range(1, num_chains + 1):
+        res[c - 1] = allv[(c - 1) % world, (c - 1) // world]
+    return res
+
+
+class ChainSet:
+    """The chains of one fit that live on this rank's GPU."""
+
+    def __init__(self, X_new, y, R, num_chains, tot_save, seed, hyper, device=None):
+        self.num_chains = num_chains
+        self.ids = local_chain_ids(num_chains)
+        dev = _default_device() if device is None else device
+        self.chains = {c: Chain(X_new, y, R, tot_save, seed, c, device=dev, **hyper) for c in self.ids}
+        self.V, self.q, self.R = (next(iter(self.chains.values())).V, next(iter(self.chains.values())).q, R) if self.chains else (None, None, R)
+
+    def init_prior(self):
+        for ch in self.chains.values():
+            ch.init_prior()
+
+    def run(self, first_index, nburn, total, purge_burn, prog_freq=0, callback=None):
+        """run! on every local chain; chains overlap on the GPU (async launch, then sync).  Chain 1 ticks the
+        progress callback (gibbs.jl:854-856) and is therefore run synchronously last."""
+        tick = [c for c in self.ids if c == 1 and callback is not None]
+        for c in self.ids:
+            if c not in tick:
+                self.chains[c].run_async(first_index, nburn, total, purge_burn)
+        for c in tick:
+            self.chains[c].run(first_index, nburn, total, purge_burn, prog_freq, callback)
+        for c in self.ids:
+            if c not in tick:
+                self.chains[c].sync()
+
+    def rhat(self, first_row, nsamp):
+        """split-Rhat over ALL chains of the fit for gamma (q) then xi (V) (return_psrf_VOI, gibbs.jl:771-789)."""
+        local = {c: ch.rhat_stats(first_row, nsamp) for c, ch in self.chains.items()}
+        allst = allgather_stats(local, self.num_chains)
+        r = rhat_from_stats(allst, nsamp)
+        q = (allst.shape[1] // 4) - self._V_from_width(allst.shape[1] // 4)
+        return r[:q], r[q:]
+
+    @staticmethod
+    def _V_from_width(npar):
+        # npar = q + V = V(V+3)/2
+        return int(round((-3 + math.sqrt(9 + 8 * npar)) / 2))
+
+    def close(self):
+        for ch in self.chains.values():
+            ch.close()
+
+
+# ------------------------------------------------------------------------------------------ chain driver
+def initialize_and_run(X, y, c, total, V, R, eta, zeta, iota, aDelta, bDelta, nu, seed, prog_freq=0, purge_burn=None,
+                       nsamp=None, callback=None, device=0):
+    """initialize_and_run! (gibbs.jl:822-846) for ONE chain c; `seed` replaces the reference's rng argument
+    (stream = seed + c).  Returns the Chain handle (the device-resident state table)."""
+    tot_save = total if purge_burn is None else nsamp + purge_burn
+    ch = Chain(X, y, R, tot_save, seed, c, device=device, eta=eta, zeta=zeta, iota=iota, aDelta=aDelta, bDelta=bDelta, nu=nu)
+    ch.init_prior()
+    nburn = total - nsamp
+    run(ch, 2, nburn, total, purge_burn, prog_freq, callback if c == 1 else None)
+    return ch
+
+
+def run(chain, first_index, nburn, total, purge_burn=None, prog_freq=0, callback=None):
+    """run! (gibbs.jl:849-864) on an existing chain."""
+    return chain.run(first_index, nburn, total, purge_burn, prog_freq, callback)
+
+
+def return_psrf_VOI(chainset, nburn, nsamp):
+    """gibbs.jl:771-789: PSRF of gamma and xi over rows nburn+1..nburn+nsamp of every chain + chain 1's table."""
+    rg, rx = chainset.rhat(nburn + 1, nsamp)
+    state = None
+    if 1 in chainset.chains:
+        ch = chainset.chains[1]
+        state = new_table(ch.tot, ch.V, ch.R, dead=True)
+        ch.fetch(1, ch.tot, state)
+    return Results(state, rx, rg, nburn, nsamp)
+
+
+class _Progress:
+    def __init__(self, total_ticks, enabled, start=0):
+        self.n, self.total, self.enabled = start, max(total_ticks, 1), enabled
+
+    def tick(self, _done=None):
+        self.n += 1
+        if self.enabled:
+            sys.stderr.write("\rProgress: %3d%%" % min(100, int(100 * self.n / self.total)))
+            sys.stderr.flush()
+
+    def done(self):
+        if self.enabled:
+            sys.stderr.write("\n")
+
+
+def _normalize_purge(purge_burn, nburn):
+    """gibbs.jl:930-936."""
+    if purge_burn is not None and purge_burn < nburn and purge_burn != 0:
+        if nburn % purge_burn != 0:
+            purge_burn = purge_burn - (nburn % purge_burn)
+        return purge_burn
+    return None
+
+
+def generate_samples(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1.0, nu=10, nburn=30000, nsamp=20000,
+                     maxburn=50000, psrf_cutoff=1.2, x_transform=True, suppress_timer=False, num_chains=2, seed=None,
+                     purge_burn=None, device=None, _keep=None):
+    """generate_samples! (gibbs.jl:897-1020): "traditional" scheme with PSRF-driven top-up rounds."""
+    if nu < R:
+        pass                                       # the reference constructs an ArgumentError without throwing it (901-902)
+    elif nu == R:
+        print("Warning: ν==R may give poor accuracy. Consider increasing ν")
+    X_new, V, q = setup_X(X, x_transform)
+    y = np.asarray(y, dtype=np.float64)
+    total = nburn + nsamp
+    prog_freq = 1000
+    if prog_freq >= nburn:
+        prog_freq = 10
+    seed_eff = random.SystemRandom().randrange(1, 2**31) if seed is None else seed      # Xoshiro() when seed===nothing
+    purge_burn = _normalize_purge(purge_burn, nburn)
+    tot_save = total if purge_burn is None else nsamp + purge_burn
+    hyper = dict(eta=eta, zeta=zeta, iota=iota, aDelta=aDelta, bDelta=bDelta, nu=nu)
+    cs = ChainSet(X_new, y, R, num_chains, tot_save, seed_eff, hyper, device)
+    if _keep is not None:
+        _keep.append(cs)
+    p = _Progress((total - 1) // prog_freq, not suppress_timer)
+    cs.init_prior()
+    cs.run(2, nburn, total, purge_burn, prog_freq, p.tick)
+    p.done()
+    tot_generated = nburn + nsamp
+    stt = purge_burn if purge_burn is not None else nburn
+    res = return_psrf_VOI(cs, stt, nsamp)
+    print("%d samples generated. Max PSRF XI: %.2f. Max PSRF Gamma: %.2f" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()), file=sys.stderr)
+    while (res.rhatxi.max() > psrf_cutoff or res.rhatgamma.max() > psrf_cutoff) and tot_generated < (maxburn + nsamp):
+        # we want to generate nburn more samples (gibbs.jl:963-974)
+        if purge_burn is not None:
+            num2move = 1 if nsamp + purge_burn <= nburn else nsamp + purge_burn - nburn
+        else:
+            num2move = total - nburn
+        tot_sze = tot_save
+        print("num2move: %d nburn: %d nsamp: %d purge_burn: %s" % (num2move, nburn, nsamp, purge_burn), file=sys.stderr)
+        p = _Progress((tot_generated + nburn - 1) // prog_freq, not suppress_timer, start=tot_generated // prog_freq)
+        for ch in cs.chains.values():
+            ch.move_rows(1, tot_sze - num2move + 1, num2move)                     # copy_table! loop :991-993
+        cs.run(num2move + 1, (nburn - nsamp + num2move) if nburn > nsamp else 0,
+               (num2move + nburn) if num2move > 1 else nburn, purge_burn, prog_freq, p.tick)   # run! :997-999
+        p.done()
+        A = (num2move + nburn) if num2move > 1 else nburn
+        B = num2move
+        tot_generated = tot_generated + A - B
+        res = return_psrf_VOI(cs, stt, nsamp)
+        print("%d samples generated. Max PSRF XI: %.3f. Max PSRF Gamma: %.3f" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()), file=sys.stderr)
+    print("R = %s nu=%s nburn= %d nsamp = %d" % (R, nu, nburn, nsamp))
+    print("%d samples generated. Max PSRF XI: %.3f. Max PSRF Gamma: %.3f\n" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()))
+    if _keep is None:
+        cs.close()
+    return res
+
+
+def generate_samples_dbl(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1.0, nu=10, mingen=10000,
+                         maxgen=100000, psrf_cutoff=1.01, x_transform=True, suppress_timer=False, num_chains=2,
+                         seed=None, purge_burn=None, device=None):
+    """generate_samples_dbl! (gibbs.jl:1051-1198): "doubling generation" scheme."""
+    if nu == R:
+        print("Warning: ν==R may give poor accuracy. Consider increasing ν")
+    nburn = _julia_round(mingen / 2)
+    nsamp = mingen - nburn
+    X_new, V, q = setup_X(X, x_transform)
+    y = np.asarray(y, dtype=np.float64)
+    total = nburn + nsamp
+    prog_freq = 1000
+    if prog_freq >= nburn:
+        prog_freq = 10
+    seed_eff = random.SystemRandom().randrange(1, 2**31) if seed is None else seed
+    purge_burn = _normalize_purge(purge_burn, nburn)
+    tot_save = total if purge_burn is None else nsamp + purge_burn
+    hyper = dict(eta=eta, zeta=zeta, iota=iota, aDelta=aDelta, bDelta=bDelta, nu=nu)
+    cs = ChainSet(X_new, y, R, num_chains, tot_save, seed_eff, hyper, device)
+    p = _Progress((total - 1) // prog_freq, not suppress_timer)
+    cs.init_prior()
+    cs.run(2, nburn, total, purge_burn, prog_freq, p.tick)
+    p.done()
+    tot_generated = nburn + nsamp
+    tot_samples = nsamp
+    stt = purge_burn if purge_burn is not None else nburn
+    res = return_psrf_VOI(cs, stt, nsamp)
+    print("%d samples generated. Max PSRF XI: %.3f. Max PSRF Gamma: %.3f" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()), file=sys.stderr)
+
+    def _bad(r):
+        return (r.rhatxi.max() > psrf_cutoff or r.rhatgamma.max() > psrf_cutoff or np.isnan(r.rhatxi.max()) or np.isnan(r.rhatgamma.max()))
+
+    while _bad(res) and tot_generated < maxgen:
+        halfburn = _julia_round(mingen / 2)
+        num2move = tot_samples                       # gibbs.jl:1143
+        tot_samples = tot_samples + halfburn
+        nsamp = tot_samples
+        tot_sze = tot_save
+        tot_save = tot_samples + halfburn
+        print("num2move: %d nburn: %d nsamp: %d tot_save: %d first_index: %d" % (num2move, nburn, nsamp, tot_save, num2move + 1), file=sys.stderr)
+        p = _Progress((tot_save - 1) // prog_freq, not suppress_timer, start=_julia_round((num2move + 1) / prog_freq))
+        for ch in cs.chains.values():
+            # new table of tot_save rows + copy_table!(state, states[c], 1:num2move, tail)  (gibbs.jl:1164-1172)
+            ch.move_rows(1, tot_sze - num2move + 1, num2move)
+            ch.resize(tot_save)
+        cs.run(num2move + 1, 0, tot_save, purge_burn, prog_freq, p.tick)           # run! :1176-1178
+        p.done()
+        tot_generated = tot_generated + mingen
+        res = return_psrf_VOI(cs, stt, nsamp)
+        print("%d samples generated. Max PSRF XI: %.3f. Max PSRF Gamma: %.3f" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()), file=sys.stderr)
+    print("\nR = %s nu=%s nburn= %d nsamp = %d\n" % (R, nu, nburn, nsamp))
+    print("%d samples generated. Max PSRF XI: %.4f. Max PSRF Gamma: %.4f" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()))
+    cs.close()
+    return res
+
+
+def Fit(X, y, R, eta=1.01, V=30, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1.0, nu=10, nburn=30000, nsamples=20000,
+        mingen=0, maxgen=0, psrf_cutoff=1.01, x_transform=True, suppress_timer=False, num_chains=2, seed=None,
+        purge_burn=None, filename="parameters.log", device=None):
+    """Fit! (gibbs.jl:725-751).  The `V` keyword is accepted and ignored, as in the reference."""
+    seed = random.randrange(1, 55556) if seed is None else seed           # sample(1:55555) :739
+    if _rank_world()[0] == 0 and filename:
+        with open(filename, "w") as f:
+            f.write("BayesianNetworkRegression.jl Fit! function\n")
+            f.write(datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S.%f")[:-3] + "\n")
+            f.write(CITATION)
+            f.write("\n\nParameters:\n")
+            f.write("R=%s, η=%s, ζ=%s, ι=%s, aΔ=%s, bΔ=%s, ν=%s, nburn=%s, nsamples=%s, \n" % (R, eta, zeta, iota, aDelta, bDelta, nu, nburn, nsamples))
+            f.write("mingen=%s, maxgen=%s, psrf_cutoff=%s, \n" % (mingen, maxgen, psrf_cutoff))
+            f.write("x_transform=%s, suppress_timer=%s, num_chains=%s, purge_burn=%s \n" % (str(x_transform).lower(), str(suppress_timer).lower(), num_chains, "nothing" if purge_burn is None else purge_burn))
+            f.write("seed=%s" % seed)
+    if mingen > 0 and maxgen > 0:
+        return generate_samples_dbl(X, y, R, eta=eta, zeta=zeta, iota=iota, aDelta=aDelta, bDelta=bDelta, nu=nu, mingen=mingen,
+                                    maxgen=maxgen, psrf_cutoff=psrf_cutoff, x_transform=x_transform, suppress_timer=suppress_timer,
+                                    num_chains=num_chains, seed=seed, purge_burn=purge_burn, device=device)
+    return generate_samples(X, y, R, eta=eta, zeta=zeta, iota=iota, aDelta=aDelta, bDelta=bDelta, nu=nu, nburn=nburn, nsamp=nsamples,
+                            maxburn=nburn + nsamples, psrf_cutoff=psrf_cutoff, x_transform=x_transform,
+                            suppress_timer=suppress_timer, num_chains=num_chains, seed=seed, purge_burn=purge_burn, device=device)

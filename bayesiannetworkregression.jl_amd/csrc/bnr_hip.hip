@@ -1,0 +1,713 @@
+// bnr_hip.hip -- C ABI (include/bnr_hip.h) over the gfx950 kernels in bnr_kernels.h.
+// Host side of one chain: allocation, the run! loop with the purge ring (gibbs.jl:849-864), the test hooks that
+// mirror the reference's update_*! functions, table fetch/load and the split-Rhat reduction.
+#include "../../include/bnr_hip.h"
+#include "bnr_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(BNR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+    } while (0)
+
+struct bnr_chain {
+    bnr_dev d{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void *> allocs;
+    bnr_plan_entry *plan_dev = nullptr, *plan_pin = nullptr;
+    int plan_cap = 0;
+    int64_t iter = 0;            // global iteration id of the last drawn row
+    int carried_row = -1;        // 0-based row whose (rr, sig_q) are in d.scal; -1 = invalid
+    int next_row = 0;            // 1-based j the next run call would write
+    bool pending = false;
+    long long *counters_host = nullptr;
+    // options
+    int use_graph = 0;
+    // profiling
+    int profiling = 0;
+    std::vector<hipEvent_t> ev;  // pairs around k_gram, plus [begin,end] of the run
+    double t_gram_us = 0, t_iter_us = 0;
+    int64_t n_gram = 0, n_iter = 0;
+    size_t trace_bytes = 0;
+};
+
+static int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+template <typename T>
+static int dev_alloc(bnr_chain *c, T **p, size_t count, bool zero = true)
+{
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    if (zero) HIPCHK(hipMemset(q, 0, std::max<size_t>(count, 1) * sizeof(T)));
+    c->allocs.push_back(q);
+    *p = (T *)q;
+    return BNR_OK;
+}
+static void forget_alloc(bnr_chain *c, void *p)
+{
+    auto it = std::find(c->allocs.begin(), c->allocs.end(), p);
+    if (it != c->allocs.end()) c->allocs.erase(it);
+}
+
+extern "C" {
+
+int bnr_abi_version(void) { return BNR_ABI_VERSION; }
+const char *bnr_last_error(void) { return g_err.c_str(); }
+int bnr_device_count(int *count)
+{
+    if (!count) return fail(BNR_ERR_BAD_ARG, "count is NULL");
+    HIPCHK(hipGetDeviceCount(count));
+    return BNR_OK;
+}
+
+void bnr_host_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    bnr_u4 r = bnr_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+void bnr_host_uniform2(uint64_t seed, uint32_t it, uint32_t site, uint32_t elem, uint32_t att, double out[2])
+{ bnr_draw2(seed, it, site, elem, att, out[0], out[1]); }
+double bnr_host_normal(uint64_t seed, uint32_t it, uint32_t site, uint32_t elem, uint32_t att)
+{ return bnr_normal(seed, it, site, elem, att); }
+double bnr_host_gamma(uint64_t seed, double shape, uint32_t it, uint32_t site, uint32_t elem)
+{ int cap = 0; return bnr_gamma(seed, shape, it, site, elem, &cap); }
+double bnr_host_gig(uint64_t seed, double lambda, double chi, double psi, uint32_t it, uint32_t elem)
+{ int cap = 0; return bnr_gig(seed, lambda, chi, psi, it, elem, &cap); }
+int32_t bnr_host_edge_index(int32_t V, int32_t l, int32_t k)
+{ return l >= k ? bnr_edge_index(V, l, k) : bnr_edge_index(V, k, l); }
+
+static int alloc_trace(bnr_chain *c, int tot, double **out)
+{
+    void *p = nullptr;
+    size_t bytes = (size_t)tot * c->d.rowlen * sizeof(double);
+    HIPCHK(hipMalloc(&p, bytes));
+    HIPCHK(hipMemset(p, 0, bytes));
+    *out = (double *)p;
+    c->trace_bytes = bytes;
+    return BNR_OK;
+}
+
+int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const double *y, const bnr_hyper *hyper,
+                     uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save, bnr_chain **out)
+{
+    if (!out || !X || !y || !hyper) return fail(BNR_ERR_BAD_ARG, "NULL argument");
+    if (n < 1 || V < 2 || R < 1 || R > BNR_RMAX || tot_save < 2)
+        return fail(BNR_ERR_BAD_ARG, "need n>=1, V>=2, 1<=R<=32, tot_save>=2");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(BNR_ERR_BAD_ARG, "no such device");
+    HIPCHK(hipSetDevice(device));
+    bnr_chain *c = new bnr_chain();
+    c->device = device;
+    bnr_dev &d = c->d;
+    d.n = n; d.V = V; d.R = R; d.q = V * (V + 1) / 2; d.tot = tot_save;
+    d.n_pad = round_up(n, BNR_GT);
+    d.ntile = d.n_pad / BNR_GT;
+    const int ntl = d.ntile * (d.ntile + 1) / 2;
+    // split K so that the Gram launch has >= ~256 workgroups (one per CU); each slice a multiple of 16 columns
+    d.ksplit = std::max(1, std::min((256 + ntl - 1) / ntl, (d.q + 63) / 64));
+    int kchunk = round_up((d.q + d.ksplit - 1) / d.ksplit, 16);
+    d.q_pad = kchunk * d.ksplit;
+    // row layout
+    int o = 4;
+    d.o_xi = o; o += V;
+    d.o_lam = o; o += R;
+    d.o_pi = o; o += 3 * R;
+    d.o_M = o; o += R * R;
+    d.o_u = o; o += R * V;
+    o = round_up(o, 16);
+    d.o_gamma = o; o += d.q;
+    o = round_up(o, 16);
+    d.o_S = o; o += d.q;
+    d.rowlen = round_up(o, 16);
+    d.eta = hyper->eta; d.zeta = hyper->zeta; d.iota = hyper->iota;
+    d.aDelta = hyper->aDelta; d.bDelta = hyper->bDelta; d.nu = hyper->nu;
+    d.seed = seed + (uint64_t)(int64_t)chain_id;
+    // GEMV pass partition
+    d.nblk_x = std::max(std::min((d.q + 31) / 32, 256), (d.q + 255) / 256);
+    d.chunk_x = (d.q + d.nblk_x - 1) / d.nblk_x;
+    d.nblk_x = (d.q + d.chunk_x - 1) / d.chunk_x;
+    d.chunk_bp = 32;
+    d.nblk_bp = (d.q + d.chunk_bp - 1) / d.chunk_bp;
+
+    int rc;
+    double *Xd = nullptr, *yd = nullptr;
+    int *ek = nullptr, *el = nullptr;
+#define TRY(x) do { rc = (x); if (rc) { bnr_chain_destroy(c); return rc; } } while (0)
+    TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess ? BNR_OK : fail(BNR_ERR_HIP, "hipStreamCreate failed"));
+    TRY(dev_alloc(c, &Xd, (size_t)d.n_pad * d.q_pad));
+    TRY(dev_alloc(c, &yd, d.n_pad));
+    TRY(dev_alloc(c, &ek, d.q));
+    TRY(dev_alloc(c, &el, d.q));
+    if (hipMemcpy2D(Xd, (size_t)d.n_pad * sizeof(double), X, (size_t)n * sizeof(double), (size_t)n * sizeof(double), d.q,
+                    hipMemcpyHostToDevice) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "copy X failed"); }
+    if (hipMemcpy(yd, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "copy y failed"); }
+    {
+        std::vector<int> hk(d.q), hl(d.q);
+        int e = 0;
+        for (int k = 0; k < V; ++k) for (int l = k; l < V; ++l, ++e) { hk[e] = k; hl[e] = l; }
+        hipMemcpy(ek, hk.data(), d.q * sizeof(int), hipMemcpyHostToDevice);
+        hipMemcpy(el, hl.data(), d.q * sizeof(int), hipMemcpyHostToDevice);
+    }
+    d.X = Xd; d.y = yd; d.ek = ek; d.el = el;
+    TRY(alloc_trace(c, tot_save, &d.trace));
+    TRY(dev_alloc(c, &d.Wbuf, d.q_pad));
+    TRY(dev_alloc(c, &d.sz, d.q_pad));
+    TRY(dev_alloc(c, &d.PW, (size_t)d.nblk_x * d.n_pad));
+    TRY(dev_alloc(c, &d.PA, (size_t)d.nblk_x * d.n_pad));
+    TRY(dev_alloc(c, &d.PG, (size_t)d.nblk_x * d.n_pad));
+    TRY(dev_alloc(c, &d.Gpart, (size_t)d.ksplit * ntl * BNR_GT * BNR_GT));
+    TRY(dev_alloc(c, &d.G, (size_t)d.n_pad * d.n_pad));
+    TRY(dev_alloc(c, &d.invD, (size_t)(d.n_pad / BNR_NB) * BNR_NB * BNR_NB));
+    TRY(dev_alloc(c, &d.a3, d.n_pad));
+    TRY(dev_alloc(c, &d.xw, d.n_pad));
+    TRY(dev_alloc(c, &d.a4, d.n_pad));
+    TRY(dev_alloc(c, &d.res, d.n_pad));
+    TRY(dev_alloc(c, &d.xg, d.n_pad));
+    TRY(dev_alloc(c, &d.scal, 16));
+    TRY(dev_alloc(c, &d.Psum, (size_t)d.nblk_bp * (1 + 3 * R)));
+    TRY(dev_alloc(c, &d.counters, 8));
+    c->plan_cap = 4096;
+    TRY(dev_alloc(c, &c->plan_dev, c->plan_cap));
+    if (hipHostMalloc((void **)&c->plan_pin, sizeof(bnr_plan_entry) * c->plan_cap) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipHostMalloc failed"); }
+    if (hipHostMalloc((void **)&c->counters_host, sizeof(long long) * 8) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipHostMalloc failed"); }
+    d.plan = c->plan_dev;
+#undef TRY
+    *out = c;
+    return BNR_OK;
+}
+
+int bnr_chain_destroy(bnr_chain *c)
+{
+    if (!c) return BNR_OK;
+    hipSetDevice(c->device);
+    if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+    for (hipEvent_t e : c->ev) hipEventDestroy(e);
+    for (void *p : c->allocs) hipFree(p);
+    if (c->d.trace) hipFree(c->d.trace);
+    if (c->plan_pin) hipHostFree(c->plan_pin);
+    if (c->counters_host) hipHostFree(c->counters_host);
+    delete c;
+    return BNR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ launch helpers
+static int ensure_plan(bnr_chain *c, int count)
+{
+    if (count <= c->plan_cap) return BNR_OK;
+    int cap = std::max(count, 2 * c->plan_cap);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    bnr_plan_entry *nd = nullptr, *np = nullptr;
+    HIPCHK(hipMalloc((void **)&nd, sizeof(bnr_plan_entry) * cap));
+    HIPCHK(hipHostMalloc((void **)&np, sizeof(bnr_plan_entry) * cap));
+    forget_alloc(c, c->plan_dev);
+    hipFree(c->plan_dev);
+    hipHostFree(c->plan_pin);
+    c->allocs.push_back(nd);
+    c->plan_dev = nd; c->plan_pin = np; c->plan_cap = cap;
+    c->d.plan = nd;
+    return BNR_OK;
+}
+static int upload_plan(bnr_chain *c, int count)
+{
+    HIPCHK(hipMemcpyAsync(c->plan_dev, c->plan_pin, sizeof(bnr_plan_entry) * count, hipMemcpyHostToDevice, c->stream));
+    return BNR_OK;
+}
+static int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(BNR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return BNR_OK;
+}
+
+static void launch_node(bnr_chain *c, int s, int mode) { hipLaunchKernelGGL(k_node, dim3(c->d.V), dim3(64), 0, c->stream, c->d, s, mode); }
+static void launch_xpass(bnr_chain *c, int s, int which)
+{ hipLaunchKernelGGL(k_xpass, dim3(c->d.nblk_x), dim3(256), 3 * c->d.chunk_x * sizeof(double), c->stream, c->d, s, which); }
+static void launch_factor(bnr_chain *c, int s, bool timed)
+{
+    const bnr_dev &d = c->d;
+    const int ntl = d.ntile * (d.ntile + 1) / 2;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        c->ev.push_back(e0); c->ev.push_back(e1);
+        hipEventRecord(e0, c->stream);
+    }
+    hipLaunchKernelGGL(k_gram, dim3(ntl, d.ksplit), dim3(256), 0, c->stream, c->d, s);
+    if (timed) hipEventRecord(e1, c->stream);
+    hipLaunchKernelGGL(k_gram_reduce, dim3(ntl), dim3(256), 0, c->stream, c->d);
+    const int nb = d.n_pad / BNR_NB;
+    for (int p = 0; p < nb; ++p) hipLaunchKernelGGL(k_chol_panel, dim3(nb - p), dim3(256), 0, c->stream, c->d, p);
+}
+static void launch_solve(bnr_chain *c, int s)
+{ hipLaunchKernelGGL(k_solve, dim3(1), dim3(1024), (c->d.n_pad + BNR_NB) * sizeof(double), c->stream, c->d, s); }
+static void launch_backproj(bnr_chain *c, int s, int flags)
+{ hipLaunchKernelGGL(k_backproj, dim3(c->d.nblk_bp), dim3(256), (c->d.n_pad + 64) * sizeof(double), c->stream, c->d, s, flags); }
+static void launch_tail(bnr_chain *c, int s, int mask, int xg_src)
+{ hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), 0, c->stream, c->d, s, mask, xg_src); }
+
+// one full sweep for plan slot s (gibbs_sample!, gibbs.jl:663-677)
+static void launch_sweep(bnr_chain *c, int s)
+{
+    launch_node(c, s, 3);
+    launch_xpass(c, s, 3);
+    launch_factor(c, s, c->profiling != 0);
+    launch_solve(c, s);
+    launch_backproj(c, s, 7);
+    launch_tail(c, s, 255, 0);
+}
+
+// (re)compute the carried sums rr, sig_q from 0-based row r (needed after init, load, hooks)
+static int refresh_carried(bnr_chain *c, int r)
+{
+    if (c->carried_row == r) return BNR_OK;
+    int rc = ensure_plan(c, 1);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->plan_pin[0] = bnr_plan_entry{0u, r, r, 0};
+    rc = upload_plan(c, 1);
+    if (rc) return rc;
+    launch_xpass(c, 0, 4);
+    launch_tail(c, 0, 64, 1);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->carried_row = r;
+    return check_launch("refresh");
+}
+
+static int fetch_status(bnr_chain *c)
+{
+    HIPCHK(hipMemcpyAsync(c->counters_host, c->d.counters, sizeof(long long) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->counters_host[3] > 0) return fail(BNR_ERR_CHOLESKY, "Cholesky failed after the jitter ladder");
+    return BNR_OK;
+}
+
+int bnr_chain_init_prior(bnr_chain *c)
+{
+    if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
+    HIPCHK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_init_prior, dim3(1), dim3(256), 0, c->stream, c->d);
+    int rc = check_launch("k_init_prior");
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->iter = 1;
+    c->carried_row = -1;
+    c->next_row = 2;
+    return BNR_OK;
+}
+
+// run! (gibbs.jl:849-864): builds the plan exactly as the reference loop walks (i, j), then enqueues the sweeps.
+static int enqueue_run(bnr_chain *c, int first_index, int nburn, int total, int purge_burn)
+{
+    if (first_index < 2 || total < first_index - 1) return fail(BNR_ERR_BAD_ARG, "need first_index>=2 and total>=first_index-1");
+    HIPCHK(hipSetDevice(c->device));
+    const int count = total - first_index + 1;
+    if (count <= 0) { c->next_row = first_index; return BNR_OK; }
+    int rc = refresh_carried(c, first_index - 2);
+    if (rc) return rc;
+    rc = ensure_plan(c, count);
+    if (rc) return rc;
+    int j = first_index, prev = first_index - 2, s = 0, maxrow = 0;
+    for (int i = first_index; i <= total; ++i, ++s) {
+        c->iter += 1;
+        bnr_plan_entry e{(uint32_t)c->iter, j - 1, prev, 0};
+        maxrow = std::max(maxrow, j);
+        prev = j - 1;
+        if (purge_burn > 0 && i < nburn && j == purge_burn + 1) { e.wrap = 1; j = 1; }   // copy_table!(state,1,j); j = 1
+        j = j + 1;
+        c->plan_pin[s] = e;
+    }
+    if (maxrow > c->d.tot) { c->iter -= count; return fail(BNR_ERR_BAD_ARG, "run would write past the table (tot_save too small)"); }
+    rc = upload_plan(c, count);
+    if (rc) return rc;
+    c->next_row = j;
+    c->carried_row = -1;
+    return BNR_OK;
+}
+
+int bnr_chain_run(bnr_chain *c, int32_t first_index, int32_t nburn, int32_t total, int32_t purge_burn,
+                  int32_t prog_freq, bnr_progress_cb cb, void *user, int32_t *next_row)
+{
+    if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
+    if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending; call bnr_chain_sync first");
+    int rc = enqueue_run(c, first_index, nburn, total, purge_burn);
+    if (rc) return rc;
+    const int count = total - first_index + 1;
+    for (hipEvent_t e : c->ev) hipEventDestroy(e);
+    c->ev.clear();
+    hipEvent_t r0 = nullptr, r1 = nullptr;
+    if (c->profiling) { hipEventCreate(&r0); hipEventCreate(&r1); hipEventRecord(r0, c->stream); }
+    for (int s = 0; s < count; ++s) {
+        launch_sweep(c, s);
+        int i = first_index + s;
+        if (cb && prog_freq > 0 && (i % prog_freq == 0)) {          // gibbs.jl:854-856
+            HIPCHK(hipStreamSynchronize(c->stream));
+            cb(user, (int64_t)(s + 1));
+        }
+    }
+    if (c->profiling) hipEventRecord(r1, c->stream);
+    rc = check_launch("sweep");
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->profiling && count > 0) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, r0, r1);
+        c->t_iter_us = 1e3 * ms / count; c->n_iter = count;
+        double acc = 0;
+        for (size_t k = 0; k + 1 < c->ev.size(); k += 2) { float m2 = 0; hipEventElapsedTime(&m2, c->ev[k], c->ev[k + 1]); acc += m2; }
+        c->n_gram = (int64_t)(c->ev.size() / 2);
+        c->t_gram_us = c->n_gram ? 1e3 * acc / c->n_gram : 0;
+        hipEventDestroy(r0); hipEventDestroy(r1);
+    }
+    if (count > 0) c->carried_row = c->plan_pin[count - 1].row;
+    if (next_row) *next_row = c->next_row;
+    return fetch_status(c);
+}
+
+int bnr_chain_run_async(bnr_chain *c, int32_t first_index, int32_t nburn, int32_t total, int32_t purge_burn)
+{
+    if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
+    if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is already pending");
+    int rc = enqueue_run(c, first_index, nburn, total, purge_burn);
+    if (rc) return rc;
+    const int count = total - first_index + 1;
+    int saved = c->profiling;
+    c->profiling = 0;
+    for (int s = 0; s < count; ++s) launch_sweep(c, s);
+    c->profiling = saved;
+    c->pending = true;
+    if (count > 0) c->carried_row = -2 - c->plan_pin[count - 1].row;    // becomes valid at sync
+    return check_launch("sweep");
+}
+
+int bnr_chain_sync(bnr_chain *c, int32_t *next_row)
+{
+    if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->pending) {
+        c->pending = false;
+        if (c->carried_row <= -2) c->carried_row = -2 - c->carried_row;
+    }
+    if (next_row) *next_row = c->next_row;
+    return fetch_status(c);
+}
+
+// ------------------------------------------------------------------------------------------ test hooks
+static int hook_begin(bnr_chain *c, int row, int64_t iter, bool need_carried)
+{
+    if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
+    if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");
+    if (row < 2 || row > c->d.tot) return fail(BNR_ERR_BAD_ARG, "row out of range (need 2 <= row <= tot_save)");
+    HIPCHK(hipSetDevice(c->device));
+    if (need_carried) { int rc = refresh_carried(c, row - 2); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->plan_pin[0] = bnr_plan_entry{(uint32_t)iter, row - 1, row - 2, 0};
+    return upload_plan(c, 1);
+}
+static int hook_end(bnr_chain *c, const char *what)
+{
+    int rc = check_launch(what);
+    if (rc) return rc;
+    c->carried_row = -1;
+    return fetch_status(c);
+}
+
+int bnr_gibbs_step(bnr_chain *c, int32_t row, int64_t iter)
+{
+    int rc = hook_begin(c, row, iter, true);
+    if (rc) return rc;
+    launch_sweep(c, 0);
+    rc = hook_end(c, "gibbs_step");
+    if (!rc) { c->carried_row = row - 1; c->iter = iter; }
+    return rc;
+}
+int bnr_update_tau2(bnr_chain *c, int32_t row, int64_t iter)
+{
+    int rc = hook_begin(c, row, iter, true);
+    if (rc) return rc;
+    launch_node(c, 0, 1);
+    return hook_end(c, "update_tau2");
+}
+int bnr_update_u_xi(bnr_chain *c, int32_t row, int64_t iter)
+{
+    int rc = hook_begin(c, row, iter, false);
+    if (rc) return rc;
+    launch_node(c, 0, 2);
+    return hook_end(c, "update_u_xi");
+}
+int bnr_update_gamma(bnr_chain *c, int32_t row, int64_t iter)
+{
+    int rc = hook_begin(c, row, iter, false);
+    if (rc) return rc;
+    launch_node(c, 0, 0);            // publishes tau = sqrt(tau2[row])
+    launch_xpass(c, 0, 3);
+    launch_factor(c, 0, false);
+    launch_solve(c, 0);
+    launch_backproj(c, 0, 1);
+    return hook_end(c, "update_gamma");
+}
+int bnr_update_D(bnr_chain *c, int32_t row, int64_t iter)
+{
+    int rc = hook_begin(c, row, iter, false);
+    if (rc) return rc;
+    launch_xpass(c, 0, 1);
+    launch_backproj(c, 0, 2);
+    return hook_end(c, "update_D");
+}
+int bnr_update_theta(bnr_chain *c, int32_t row, int64_t iter)
+{
+    int rc = hook_begin(c, row, iter, false);
+    if (rc) return rc;
+    launch_xpass(c, 0, 1);
+    launch_backproj(c, 0, 4);
+    launch_tail(c, 0, 1, 0);
+    return hook_end(c, "update_theta");
+}
+int bnr_update_Delta(bnr_chain *c, int32_t row, int64_t iter)
+{
+    int rc = hook_begin(c, row, iter, false);
+    if (rc) return rc;
+    launch_tail(c, 0, 2, 0);
+    return hook_end(c, "update_Delta");
+}
+int bnr_update_M(bnr_chain *c, int32_t row, int64_t iter)
+{
+    int rc = hook_begin(c, row, iter, false);
+    if (rc) return rc;
+    launch_tail(c, 0, 4, 0);
+    return hook_end(c, "update_M");
+}
+int bnr_update_mu(bnr_chain *c, int32_t row, int64_t iter)
+{
+    int rc = hook_begin(c, row, iter, false);
+    if (rc) return rc;
+    launch_xpass(c, 0, 4);
+    launch_tail(c, 0, 8, 1);
+    return hook_end(c, "update_mu");
+}
+int bnr_update_Lambda(bnr_chain *c, int32_t row, int64_t iter)
+{
+    int rc = hook_begin(c, row, iter, false);
+    if (rc) return rc;
+    launch_xpass(c, 0, 1);
+    launch_backproj(c, 0, 4);
+    launch_tail(c, 0, 16, 0);
+    return hook_end(c, "update_Lambda");
+}
+int bnr_update_pi(bnr_chain *c, int32_t row, int64_t iter)
+{
+    int rc = hook_begin(c, row, iter, false);
+    if (rc) return rc;
+    launch_tail(c, 0, 32, 0);
+    return hook_end(c, "update_pi");
+}
+
+int bnr_chain_get_iter(bnr_chain *c, int64_t *iter)
+{
+    if (!c || !iter) return fail(BNR_ERR_BAD_ARG, "NULL argument");
+    *iter = c->iter;
+    return BNR_OK;
+}
+int bnr_chain_set_iter(bnr_chain *c, int64_t iter)
+{
+    if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
+    c->iter = iter;
+    return BNR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ table I/O
+struct col_desc { int off, ncols; };
+static void col_layout(const bnr_dev &d, col_desc out[11])
+{
+    out[0] = {ROW_TAU2, 1}; out[1] = {d.o_u, d.R * d.V}; out[2] = {d.o_xi, d.V}; out[3] = {d.o_gamma, d.q};
+    out[4] = {d.o_S, d.q}; out[5] = {ROW_THETA, 1}; out[6] = {ROW_DELTA, 1}; out[7] = {d.o_M, d.R * d.R};
+    out[8] = {ROW_MU, 1}; out[9] = {d.o_lam, d.R}; out[10] = {d.o_pi, 3 * d.R};
+}
+
+static int table_io(bnr_chain *c, bool fetch, int first_row, int last_row, int host_tot, int host_off, double *cols[11])
+{
+    if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
+    if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");
+    const bnr_dev &d = c->d;
+    if (first_row < 1 || last_row > d.tot || last_row < first_row) return fail(BNR_ERR_BAD_ARG, "row range outside the device table");
+    const int nrows = last_row - first_row + 1;
+    if (first_row + host_off < 1 || last_row + host_off > host_tot) return fail(BNR_ERR_BAD_ARG, "row range outside the host table");
+    HIPCHK(hipSetDevice(c->device));
+    col_desc cdsc[11];
+    col_layout(d, cdsc);
+    const size_t stage_doubles = (size_t)8 << 20;     // 64 MiB staging
+    int cols_per = (int)std::max<size_t>(1, stage_doubles / (size_t)nrows);
+    double *stage = nullptr;
+    HIPCHK(hipMalloc((void **)&stage, sizeof(double) * (size_t)nrows * std::min(cols_per, std::max(d.q, d.R * d.V))));
+    int rc = BNR_OK;
+    for (int k = 0; k < 11 && !rc; ++k) {
+        if (!cols[k]) continue;
+        for (int c0 = 0; c0 < cdsc[k].ncols && !rc; c0 += cols_per) {
+            int nc = std::min(cols_per, cdsc[k].ncols - c0);
+            dim3 grid((nc + 31) / 32, (nrows + 31) / 32), block(32, 8);
+            double *hbase = cols[k] + (size_t)(first_row - 1 + host_off) + (size_t)host_tot * c0;
+            hipError_t e;
+            if (fetch) {
+                hipLaunchKernelGGL(k_fetch_cols, grid, block, 0, c->stream, (const double *)d.trace, d.rowlen, cdsc[k].off + c0, nc, first_row - 1, nrows, stage);
+                e = hipMemcpy2DAsync(hbase, (size_t)host_tot * sizeof(double), stage, (size_t)nrows * sizeof(double),
+                                     (size_t)nrows * sizeof(double), nc, hipMemcpyDeviceToHost, c->stream);
+            } else {
+                e = hipMemcpy2DAsync(stage, (size_t)nrows * sizeof(double), hbase, (size_t)host_tot * sizeof(double),
+                                     (size_t)nrows * sizeof(double), nc, hipMemcpyHostToDevice, c->stream);
+                hipLaunchKernelGGL(k_load_cols, grid, block, 0, c->stream, d.trace, d.rowlen, cdsc[k].off + c0, nc, first_row - 1, nrows, (const double *)stage);
+            }
+            if (e != hipSuccess) rc = fail(BNR_ERR_HIP, std::string("table copy: ") + hipGetErrorString(e));
+            if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(BNR_ERR_HIP, "table copy sync failed");
+        }
+    }
+    hipFree(stage);
+    if (!fetch) c->carried_row = -1;
+    return rc ? rc : check_launch("table_io");
+}
+
+int bnr_chain_fetch(bnr_chain *c, int32_t first_row, int32_t last_row, int32_t host_tot, int32_t host_row_offset,
+                    double *tau2, double *u, double *xi, double *gamma, double *S, double *theta, double *Delta,
+                    double *M, double *mu, double *lam, double *pi)
+{
+    double *cols[11] = {tau2, u, xi, gamma, S, theta, Delta, M, mu, lam, pi};
+    return table_io(c, true, first_row, last_row, host_tot, host_row_offset, cols);
+}
+int bnr_chain_load(bnr_chain *c, int32_t first_row, int32_t last_row, int32_t host_tot, int32_t host_row_offset,
+                   const double *tau2, const double *u, const double *xi, const double *gamma, const double *S,
+                   const double *theta, const double *Delta, const double *M, const double *mu, const double *lam,
+                   const double *pi)
+{
+    double *cols[11] = {(double *)tau2, (double *)u, (double *)xi, (double *)gamma, (double *)S, (double *)theta,
+                        (double *)Delta, (double *)M, (double *)mu, (double *)lam, (double *)pi};
+    return table_io(c, false, first_row, last_row, host_tot, host_row_offset, cols);
+}
+
+int bnr_chain_move_rows(bnr_chain *c, int32_t to_row, int32_t from_row, int32_t count)
+{
+    if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
+    if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");
+    const bnr_dev &d = c->d;
+    if (count < 0 || to_row < 1 || from_row < 1 || to_row + count - 1 > d.tot || from_row + count - 1 > d.tot)
+        return fail(BNR_ERR_BAD_ARG, "row range outside the device table");
+    if (count == 0 || to_row == from_row) return BNR_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t rb = (size_t)d.rowlen * sizeof(double);
+    // the reference copies row by row in increasing i (gibbs.jl:991-993): emulate exactly, also when ranges overlap
+    for (int i = 0; i < count; ++i)
+        HIPCHK(hipMemcpyAsync(d.trace + (size_t)(to_row - 1 + i) * d.rowlen, d.trace + (size_t)(from_row - 1 + i) * d.rowlen, rb,
+                              hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->carried_row = -1;
+    return BNR_OK;
+}
+
+int bnr_chain_resize(bnr_chain *c, int32_t new_tot)
+{
+    if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
+    if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");
+    if (new_tot < 2) return fail(BNR_ERR_BAD_ARG, "new_tot must be >= 2");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    bnr_dev &d = c->d;
+    double *old = d.trace, *nt = nullptr;
+    int rc = alloc_trace(c, new_tot, &nt);
+    if (rc) return rc;
+    size_t keep = (size_t)std::min(new_tot, d.tot) * d.rowlen * sizeof(double);
+    HIPCHK(hipMemcpy(nt, old, keep, hipMemcpyDeviceToDevice));
+    hipFree(old);
+    d.trace = nt; d.tot = new_tot;
+    return BNR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ Rhat
+int bnr_chain_rhat_stats(bnr_chain *c, int32_t first_row, int32_t nsamp, double *stats)
+{
+    if (!c || !stats) return fail(BNR_ERR_BAD_ARG, "NULL argument");
+    if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");
+    const bnr_dev &d = c->d;
+    if (first_row < 1 || nsamp < 4 || first_row + nsamp - 1 > d.tot) return fail(BNR_ERR_BAD_ARG, "row window outside the table or nsamp < 4");
+    HIPCHK(hipSetDevice(c->device));
+    const int np = d.q + d.V;
+    double *out = nullptr;
+    HIPCHK(hipMalloc((void **)&out, sizeof(double) * 4 * np));
+    hipLaunchKernelGGL(k_rhat_stats, dim3((np + 127) / 128), dim3(128), 0, c->stream, c->d, first_row - 1, nsamp, out);
+    hipError_t e = hipMemcpyAsync(stats, out, sizeof(double) * 4 * np, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(out);
+    if (e != hipSuccess) return fail(BNR_ERR_HIP, std::string("rhat_stats: ") + hipGetErrorString(e));
+    return check_launch("k_rhat_stats");
+}
+
+int bnr_rhat_from_stats(const double *stats, int32_t nchains, int32_t nparams, int32_t nsamp, double *rhat)
+{
+    if (!stats || !rhat || nchains < 1 || nparams < 1) return fail(BNR_ERR_BAD_ARG, "bad argument");
+    const int h = nsamp / 2, m = 2 * nchains;
+    if (h - 1 <= 0) { for (int p = 0; p < nparams; ++p) rhat[p] = NAN; return BNR_OK; }
+    const double cf = (double)(h - 1) / h;                       // convergence.jl:25
+    for (int p = 0; p < nparams; ++p) {
+        double W = 0.0, mm = 0.0;
+        for (int c = 0; c < nchains; ++c) {
+            const double *s = stats + (size_t)c * 4 * nparams;
+            mm += s[p] + s[(size_t)2 * nparams + p];
+            W += s[(size_t)nparams + p] + s[(size_t)3 * nparams + p];
+        }
+        W /= m; mm /= m;                                         // :49
+        double B = 0.0;
+        for (int c = 0; c < nchains; ++c) {
+            const double *s = stats + (size_t)c * 4 * nparams;
+            double d0 = s[p] - mm, d1 = s[(size_t)2 * nparams + p] - mm;
+            B += d0 * d0 + d1 * d1;
+        }
+        B /= (m - 1);
+        double varp = cf * W + B;                                // :52
+        if (varp == 0.0 && W == 0.0) rhat[p] = 1.0;              // :55-61
+        else if (W == 0.0) rhat[p] = INFINITY;
+        else rhat[p] = sqrt(varp / W);
+    }
+    return BNR_OK;
+}
+
+int bnr_chain_counters(bnr_chain *c, int64_t out[8])
+{
+    if (!c || !out) return fail(BNR_ERR_BAD_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(c->counters_host, c->d.counters, sizeof(long long) * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) out[i] = c->counters_host[i];
+    return BNR_OK;
+}
+
+int bnr_chain_set_profiling(bnr_chain *c, int32_t enable)
+{
+    if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
+    c->profiling = enable;
+    return BNR_OK;
+}
+int bnr_chain_last_timing(bnr_chain *c, int32_t which, double *avg_us, int64_t *launches)
+{
+    if (!c || !avg_us) return fail(BNR_ERR_BAD_ARG, "NULL argument");
+    if (which == 0) { *avg_us = c->t_iter_us; if (launches) *launches = c->n_iter; }
+    else if (which == 1) { *avg_us = c->t_gram_us; if (launches) *launches = c->n_gram; }
+    else return fail(BNR_ERR_BAD_ARG, "which must be 0 or 1");
+    return BNR_OK;
+}
+
+int bnr_chain_set_option(bnr_chain *c, const char *name, int64_t value)
+{
+    if (!c || !name) return fail(BNR_ERR_BAD_ARG, "NULL argument");
+    if (!strcmp(name, "graph")) { c->use_graph = (int)value; return BNR_OK; }
+    return fail(BNR_ERR_BAD_ARG, std::string("unknown option ") + name);
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+/*
+ * bnr_hip.h -- C ABI of libbnr_hip.so: the MI355X (gfx950) implementation of the Gibbs hot path of
+ * BayesianNetworkRegression.jl (reference: src/gibbs.jl + src/gig.jl + src/convergence.jl).
+ *
+ * The reference is pure Julia and has no FFI seam; this header IS the seam a maintainer would bind with
+ * `ccall` (julia/BNRHip.jl) and that the Python host mirror binds with ctypes
+ * (bayesiannetworkregression.jl_amd/_capi.py).  Every entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the ABI; every call returns an int status (BNR_OK == 0);
+ *     bnr_last_error() gives a thread-local message for the last non-zero status.
+ *   - all floating point data is IEEE double, as in the reference (gibbs.jl:835-841).
+ *   - host matrices are COLUMN-MAJOR (Julia `Matrix` memory): X is n x q with q = V(V+1)/2 columns in the
+ *     column-wise lower-triangle order of utils.jl:50-55.
+ *   - state tables handed to bnr_chain_fetch/bnr_chain_load use the reference layout
+ *     Array{Float64,3}(tot_save,d1,d2), column-major, ITERATION INDEX FASTEST.
+ *   - row/iteration indices are 1-based exactly as in run! (gibbs.jl:849-864) unless stated otherwise.
+ *   - a handle is used by one host thread at a time; different handles may be driven concurrently.
+ *   - the caller keeps ownership of every host buffer; the library owns all device memory of a chain until
+ *     bnr_chain_destroy.
+ */
+#ifndef BNR_HIP_H
+#define BNR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BNR_ABI_VERSION 1
+
+enum {
+    BNR_OK = 0,
+    BNR_ERR_BAD_ARG = 1,
+    BNR_ERR_HIP = 2,          /* a HIP runtime call failed (no device, out of memory, launch failure ...) */
+    BNR_ERR_CHOLESKY = 3,     /* Cholesky failed after the jitter ladder (the reference rethrows: gibbs.jl:337-343) */
+    BNR_ERR_SAMPLER_CAP = 4   /* a rejection sampler hit its attempt cap */
+};
+
+typedef struct bnr_chain bnr_chain;   /* opaque: one Gibbs chain resident on one GPU */
+
+/* hyper-parameters of Fit!/generate_samples! (gibbs.jl:725-727, 897-899) */
+typedef struct {
+    double eta, zeta, iota, aDelta, bDelta, nu;
+} bnr_hyper;
+
+/* progress callback: called from the calling host thread every prog_freq iterations
+ * (the reference's `put!(channel,true)`, gibbs.jl:854-856).  `done` = iterations completed in this call. */
+typedef void (*bnr_progress_cb)(void *user, int64_t done);
+
+int bnr_abi_version(void);
+const char *bnr_last_error(void);
+int bnr_device_count(int *count);
+
+/* Allocate a chain: copies X (n x q col-major) and y to HBM, allocates the tot_save-row state table and all
+ * work space on `device`.  Replaces the allocation half of initialize_and_run! (gibbs.jl:822-841).
+ * The RNG stream is keyed by seed + chain_id (the reference's Xoshiro(seed+c), gibbs.jl:928). */
+int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const double *y, const bnr_hyper *hyper,
+                     uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save, bnr_chain **out);
+int bnr_chain_destroy(bnr_chain *chain);
+
+/* initialize_variables! (gibbs.jl:191-224): draws row 1 from the priors; sets the iteration counter to 1. */
+int bnr_chain_init_prior(bnr_chain *chain);
+
+/* run! (gibbs.jl:849-864): for i in first_index:total { gibbs_sample!(row j); purge ring }.
+ * purge_burn <= 0 means `nothing`.  Synchronous.  *next_row (optional) receives the row index j the next
+ * call would write.  cb may be NULL. */
+int bnr_chain_run(bnr_chain *chain, int32_t first_index, int32_t nburn, int32_t total, int32_t purge_burn,
+                  int32_t prog_freq, bnr_progress_cb cb, void *user, int32_t *next_row);
+/* same, but only enqueues the work on the chain's stream(s); pair with bnr_chain_sync.  Lets several chains
+ * that share one GPU overlap (the reference runs chains concurrently under pmap, gibbs.jl:946). */
+int bnr_chain_run_async(bnr_chain *chain, int32_t first_index, int32_t nburn, int32_t total, int32_t purge_burn);
+int bnr_chain_sync(bnr_chain *chain, int32_t *next_row);
+
+/* gibbs_sample!(state, row, ...) (gibbs.jl:663-677) for one row, and the ten update_*! functions in sweep
+ * order (gibbs.jl:267-636): test hooks mirroring test/init-tests.jl:76,96-124.  `row` is 1-based (>= 2);
+ * `iter` is the global iteration id that keys the RNG counter for this row. */
+int bnr_gibbs_step(bnr_chain *chain, int32_t row, int64_t iter);
+int bnr_update_tau2(bnr_chain *chain, int32_t row, int64_t iter);
+int bnr_update_u_xi(bnr_chain *chain, int32_t row, int64_t iter);
+int bnr_update_gamma(bnr_chain *chain, int32_t row, int64_t iter);
+int bnr_update_D(bnr_chain *chain, int32_t row, int64_t iter);
+int bnr_update_theta(bnr_chain *chain, int32_t row, int64_t iter);
+int bnr_update_Delta(bnr_chain *chain, int32_t row, int64_t iter);
+int bnr_update_M(bnr_chain *chain, int32_t row, int64_t iter);
+int bnr_update_mu(bnr_chain *chain, int32_t row, int64_t iter);
+int bnr_update_Lambda(bnr_chain *chain, int32_t row, int64_t iter);
+int bnr_update_pi(bnr_chain *chain, int32_t row, int64_t iter);
+
+/* iteration counter (global id of the last drawn row; init row = 1) */
+int bnr_chain_get_iter(bnr_chain *chain, int64_t *iter);
+int bnr_chain_set_iter(bnr_chain *chain, int64_t iter);
+
+/* Copy rows first_row..last_row (1-based, inclusive) of the device table into / out of host arrays laid out as
+ * the reference's state Table: 11 live columns tau2(.,1,1) u(.,R,V) xi(.,V,1) gamma(.,q,1) S(.,q,1) theta Delta
+ * M(.,R,R) mu lam(.,R,1) pi(.,R,3), each Array{Float64,3}(host_tot,d1,d2).  Host row = device row + host_row_offset.
+ * The 3 dead columns of the reference (Sigma^-1, invC, mu_t: allocated, never written, utils.jl:72-84) are the
+ * caller's business.  Any column pointer may be NULL (skipped). */
+int bnr_chain_fetch(bnr_chain *chain, int32_t first_row, int32_t last_row, int32_t host_tot, int32_t host_row_offset,
+                    double *tau2, double *u, double *xi, double *gamma, double *S, double *theta, double *Delta,
+                    double *M, double *mu, double *lam, double *pi);
+int bnr_chain_load(bnr_chain *chain, int32_t first_row, int32_t last_row, int32_t host_tot, int32_t host_row_offset,
+                   const double *tau2, const double *u, const double *xi, const double *gamma, const double *S,
+                   const double *theta, const double *Delta, const double *M, const double *mu, const double *lam,
+                   const double *pi);
+
+/* copy_table!(table, to, from) for `count` consecutive rows on the device (utils.jl:72-84; used by the
+ * continuation loops gibbs.jl:991-993, 1172).  Overlap-safe. */
+int bnr_chain_move_rows(bnr_chain *chain, int32_t to_row, int32_t from_row, int32_t count);
+/* Re-allocate the device table with new_tot rows, keeping rows 1..min(old,new) (generate_samples_dbl!
+ * allocates a new table per round, gibbs.jl:1164-1172). */
+int bnr_chain_resize(bnr_chain *chain, int32_t new_tot);
+
+/* split-Rhat, first half of rhat() (convergence.jl:4-65) done on the device for ONE chain: for every parameter
+ * p of gamma (q) then xi (V) over rows first_row..first_row+nsamp-1, the mean and the corrected variance of the
+ * first floor(nsamp/2) and the last floor(nsamp/2) samples.  stats (host): 4*(q+V) doubles, laid out
+ * [mean_h0(q+V) | var_h0(q+V) | mean_h1(q+V) | var_h1(q+V)].  This is the per-chain message that is
+ * all-gathered across ranks (RCCL via torch.distributed in the host layer). */
+int bnr_chain_rhat_stats(bnr_chain *chain, int32_t first_row, int32_t nsamp, double *stats);
+/* second half: combine nchains messages (host arrays, chain-major) into Rhat per parameter.  Pure host code.
+ * rhat: q+V doubles (gamma first, then xi).  Replaces convergence.jl:49-61. */
+int bnr_rhat_from_stats(const double *stats, int32_t nchains, int32_t nparams, int32_t nsamp, double *rhat);
+
+/* event counters: out[0]=Cholesky jitter events, out[1]=NaN-weight events (always 0: log-space weights),
+ * out[2]=sampler attempt-cap events, out[3]=Cholesky hard failures, out[4..7] reserved */
+int bnr_chain_counters(bnr_chain *chain, int64_t out[8]);
+
+/* kernel timing: average device time in microseconds of the kernels of the last bnr_chain_run call, measured
+ * with HIP events on the chain's own stream.  which: 0 = whole iteration, 1 = Gram kernel (X diag(S) X'). */
+int bnr_chain_set_profiling(bnr_chain *chain, int32_t enable);
+int bnr_chain_last_timing(bnr_chain *chain, int32_t which, double *avg_us, int64_t *launches);
+
+/* tunables (performance only; never change results): name = "gram_ksplit", "graph", "overlap" ... */
+int bnr_chain_set_option(bnr_chain *chain, const char *name, int64_t value);
+
+/* Host-side copies of the draw-site primitives (same source as the device functions), exported so that the
+ * CPU test-suite can check the product's RNG contract against the oracle without a GPU. */
+void bnr_host_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void bnr_host_uniform2(uint64_t seed, uint32_t it, uint32_t site, uint32_t elem, uint32_t att, double out[2]);
+double bnr_host_normal(uint64_t seed, uint32_t it, uint32_t site, uint32_t elem, uint32_t att);
+double bnr_host_gamma(uint64_t seed, double shape, uint32_t it, uint32_t site, uint32_t elem);
+double bnr_host_gig(uint64_t seed, double lambda, double chi, double psi, uint32_t it, uint32_t elem);
+int32_t bnr_host_edge_index(int32_t V, int32_t l, int32_t k);   /* 0-based (l,k) -> 0-based e; utils.jl:50-55 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BNR_HIP_H */
