@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""bench.py -- Gibbs iterations/s (all chains) of the MI355X hot path on BASELINE.json's headline workload.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one Gibbs sweep (gibbs_sample!, gibbs.jl:663-677) of every chain resident on the GPU.  Workload: synthetic
+n=500, V=100 (q=5050), R=7 (SURVEY.md 8d generator, seed 20240501), one chain per GPU (BASELINE.json configs[2]:
+"8 chains on 8xMI355X, one chain/GPU"), weak scaling: per-GPU work is fixed, chains are independent, no data-path
+collective; after the timed region the per-chain split-Rhat messages are all-gathered over RCCL (reported, not timed).
+Inputs are resident in HBM when the timed region starts.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    "cfg2": dict(n=200, V=50, R=5),
+    "cfg3": dict(n=500, V=100, R=7),       # headline (BASELINE.json metric)
+    "cfg4": dict(n=2000, V=200, R=7),
+    "cfg5": dict(n=500, V=300, R=10),
+}
+FP64_MFMA_PEAK_TFLOPS = 78.6               # AMD MI355X FP64 matrix spec (not in the local guide)
+
+
+def cpu_baseline(X, y, R, seed, budget_s=15.0):
+    """The CPU oracle in reference-cost mode (full 2n^2 q GEMM, LU solve, dense (V-1)-dim pdfs) on the host cores."""
+    from oracle import bnr_oracle as bo
+    tot = 64
+    o = bo.Oracle(X, y, R, tot, seed, chain=1, pdf_mode=0, cost_mode=1)
+    o.init_prior()
+    t0 = time.time()
+    done = 0
+    while done < tot - 1 and (done < 2 or time.time() - t0 < budget_s):
+        o.gibbs_sample(done + 1, done + 2)
+        done += 1
+    dt = time.time() - t0
+    return dict(value=done / dt, unit="Gibbs iterations/s (1 chain)", cores=bo.lib().orc_num_threads(), kind="port",
+                sample="%d iterations of the same n/V/R workload, 1 chain, OpenMP over the Gram columns" % done)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--chains-per-gpu", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=20240501)
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import bnr_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if a.gpus > 1 or world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    cfg = CONFIGS[a.config]
+    n, V, R = cfg["n"], cfg["V"], cfg["R"]
+    q = V * (V + 1) // 2
+    X, y, _truth = bnr_amd.make_synthetic(n, V, R, seed=a.seed)
+    K, W, C = a.steps, a.warmup, a.chains_per_gpu
+    tot = W + K + 1
+    chains = []
+    for lc in range(C):
+        cid = rank * C + lc + 1                                   # chain c uses stream seed + c (gibbs.jl:928)
+        ch = bnr_amd.Chain(X, y, R, tot, a.seed, cid, device=local_rank)
+        ch.init_prior()
+        chains.append(ch)
+
+    def run_all(first, last, profile=False):
+        if profile:
+            chains[0].set_profiling(True)
+        for ch in chains[1:]:
+            ch.run_async(first, last, last)
+        chains[0].run(first, last, last)
+        for ch in chains[1:]:
+            ch.sync()
+        if profile:
+            chains[0].set_profiling(False)
+
+    if W > 0:
+        run_all(2, W + 1)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_all(W + 2, W + K + 1, profile=True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    gram_us, gram_n = chains[0].last_timing(1)
+    counters = chains[0].counters()
+
+    # convergence check over all chains of the job: RCCL all-gather of the per-chain split-Rhat messages
+    nsamp = K
+    local = {rank * C + lc + 1: ch.rhat_stats(W + 2, nsamp) for lc, ch in enumerate(chains)}
+    if dist:
+        stats = bnr_amd.allgather_stats(local, world * C)
+    else:
+        stats = np.stack([local[c] for c in sorted(local)])
+    rh = bnr_amd.rhat_from_stats(stats, nsamp)
+
+    if rank == 0:
+        total_chains = world * C
+        value = total_chains * K / dt
+        flops_gram = float(n) * n * q                             # algorithmic: symmetric X diag(S) X' 
+        achieved = flops_gram / (gram_us * 1e-6) / 1e12 if gram_us > 0 else 0.0
+        out = {
+            "metric": "Gibbs iterations/sec (all chains)", "value": value, "unit": "iterations/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic n=%d V=%d (q=%d) R=%d, %d chain(s) per GPU, %d chains total" % (n, V, q, R, C, total_chains),
+                       "chains_per_gpu": C, "seed": a.seed},
+            "roofline": {"bound": "mfma", "kernel": "k_gram (X diag(S) X', v_mfma_f64_16x16x4_f64)", "achieved": achieved,
+                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "flops_per_launch": flops_gram, "avg_launch_us": gram_us, "launches_timed": gram_n},
+            "max_rhat_gamma": float(np.nanmax(rh[:q])), "max_rhat_xi": float(np.nanmax(rh[q:])),
+            "counters": counters,
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(X, y, R, a.seed)
+        print(json.dumps(out))
+    for ch in chains:
+        ch.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
