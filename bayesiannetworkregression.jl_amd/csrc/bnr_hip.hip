@@ -550,7 +550,9 @@ static int table_io(bnr_chain *c, bool fetch, int first_row, int last_row, int h
     const size_t stage_doubles = (size_t)8 << 20;     // 64 MiB staging
     int cols_per = (int)std::max<size_t>(1, stage_doubles / (size_t)nrows);
     double *stage = nullptr;
-    HIPCHK(hipMalloc((void **)&stage, sizeof(double) * (size_t)nrows * std::min(cols_per, std::max(d.q, d.R * d.V))));
+    int widest = 1;
+    for (int k = 0; k < 11; ++k) widest = std::max(widest, cdsc[k].ncols);
+    HIPCHK(hipMalloc((void **)&stage, sizeof(double) * (size_t)nrows * std::min(cols_per, widest)));
     int rc = BNR_OK;
     for (int k = 0; k < 11 && !rc; ++k) {
         if (!cols[k]) continue;

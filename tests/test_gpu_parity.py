@@ -1,0 +1,311 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path through the C ABI against the CPU oracle on the same
+seeded inputs, against the golden fixtures, and -- at BASELINE.json's full sizes -- through size-independent
+properties.
+
+Tolerance (floating point, stated by north_star as an MCMC tolerance): the draw-site contract makes the HIP sampler
+consume the very same variates as the oracle, so the bar used here is far tighter than distributional agreement:
+every state column of every row within RTOL = 1e-6 relative (+ATOL) of the oracle over whole short runs (observed:
+<= 2e-9), discrete columns (xi, lambda) exactly equal.  Distributional agreement with the REFERENCE is then inherited from
+the oracle's own pins (tests/test_oracle_golden.py) and re-checked directly by PIT calibration of a GPU trace.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import bnr_amd
+from oracle import bnr_oracle as bo
+from pit import pit_trace
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RTOL, ATOL = 1e-6, 1e-9
+HOOKS = ["tau2", "u_xi", "gamma", "D", "theta", "Delta", "M", "mu", "Lambda", "pi"]
+HOOK_COLS = dict(tau2=["tau2"], u_xi=["u", "xi"], gamma=["gamma"], D=["S"], theta=["theta"], Delta=["Delta"], M=["M"],
+                 mu=["mu"], Lambda=["lam"], pi=["pi"])
+
+
+def assert_tables_close(got, ref, rows_got=slice(None), rows_ref=slice(None), what=""):
+    for k in bo.COLUMNS:
+        a, b = got[k][rows_got], ref[k][rows_ref]
+        assert a.shape == b.shape, (what, k, a.shape, b.shape)
+        assert np.all(np.isfinite(a)), (what, k, "non-finite")
+        if k in ("xi", "lam"):
+            assert np.array_equal(a, b), (what, k, "discrete column differs")
+        else:
+            err = np.abs(a - b) / (ATOL / RTOL + np.abs(b))
+            assert err.max() < RTOL, (what, k, float(err.max()))
+
+
+def pair(X, y, R, tot, seed, chain=1, **hyper):
+    ch = bnr_amd.Chain(X, y, R, tot, seed, chain, device=0, **hyper)
+    o = bo.Oracle(X, y, R, tot, seed, chain=chain, pdf_mode=1, **hyper)
+    return ch, o
+
+
+@pytest.fixture(scope="module")
+def test1():
+    d = np.load(os.path.join(G, "test1_xy.npz"))
+    return d["X"], d["y"]
+
+
+CASES = [  # n, V, R, rows, normal_x   (ragged n vs the 64-row tiles, tiny V, R = 1, R > V ...)
+    (40, 8, 3, 12, False), (70, 19, 5, 30, True), (1, 2, 1, 6, False), (3, 2, 4, 6, True), (65, 5, 2, 8, False),
+    (129, 12, 7, 8, True), (200, 50, 5, 10, False), (64, 33, 10, 6, True),
+]
+
+
+@pytest.mark.parametrize("n,V,R,tot,normal_x", CASES)
+def test_full_sweep_matches_oracle(gpu, n, V, R, tot, normal_x):
+    X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=1000 + n + V, normal_x=normal_x)
+    ch, o = pair(X, y, R, tot, 4242)
+    ch.init_prior()
+    o.init_prior()
+    assert_tables_close(ch.fetch(1, 1), o.t, rows_ref=slice(0, 1), what="init row")
+    nxt = ch.run(2, tot, tot)
+    assert nxt == tot + 1 == o.run(2, tot, tot)
+    assert_tables_close(ch.fetch(), o.t, what="run n=%d V=%d R=%d" % (n, V, R))
+    c = ch.counters()
+    assert c["chol_fail"] == 0 and c["sampler_cap"] == 0 and c["nan_w"] == 0
+    ch.close()
+
+
+@pytest.mark.parametrize("n,V,R,normal_x", [(40, 8, 3, False), (70, 19, 5, True), (4, 4, 7, True)])
+def test_deconstructed_sweep_matches_oracle(gpu, n, V, R, normal_x):
+    """Each update_*! called separately in sweep order on one row, as test/init-tests.jl:96-124 does."""
+    X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=31, normal_x=normal_x)
+    ch, o = pair(X, y, R, 5, 123)
+    ch.init_prior()
+    o.init_prior()
+    for row in (2, 3):
+        for name in HOOKS:
+            ch.update(name, row, row)
+            o.update(name, row - 1, row)
+            g = ch.fetch(row, row)
+            for k in HOOK_COLS[name]:
+                a, b = g[k][0], o.t[k][row - 1]
+                assert np.allclose(a, b, rtol=RTOL, atol=ATOL), (row, name, k)
+    # one gibbs_sample! on the next row (init-tests.jl:76) continues from the hook-built rows
+    ch.gibbs_step(4, 4)
+    o.gibbs_sample(3, 4)
+    assert_tables_close(ch.fetch(4, 4), o.t, rows_ref=slice(3, 4), what="gibbs_step")
+    ch.close()
+
+
+def test_test1_csv_trace_matches_oracle_and_is_calibrated(gpu, test1):
+    """test/data/test1.csv (n=70, V=19, R=5; the only reference suite that can fail CI): 400 rows on the GPU equal the
+    oracle's, and the GPU trace passes the same PIT calibration the golden reference trace passes."""
+    X, y = test1
+    ch, o = pair(X, y, 5, 400, 1234)
+    ch.init_prior()
+    o.init_prior()
+    ch.run(2, 200, 400)
+    o.run(2, 200, 400)
+    got = ch.fetch()
+    assert_tables_close(got, o.t, what="test1")
+    out = pit_trace(got, X, y, 5)
+    for k, v in out.items():
+        if k.startswith("_"):
+            continue
+        if v[0] == "calibration_z":
+            assert abs(v[1]) < 4.0, (k, v)
+        else:
+            assert v[1] > 1e-3, (k, v)
+    # split-Rhat on the device == rhat() of the oracle on the fetched table (convergence.jl:4-65)
+    st = ch.rhat_stats(201, 200)
+    r = bnr_amd.rhat_from_stats(st[None, :], 200)
+    assert np.allclose(r[:190], bo.rhat(got["gamma"][200:400, :, 0][:, :, None]), rtol=1e-10)
+    assert np.allclose(r[190:], bo.rhat(got["xi"][200:400, :, 0][:, :, None]), rtol=1e-10)
+    ch.close()
+
+
+def test_purge_ring_and_continuation(gpu, test1):
+    X, y = test1
+    nburn, nsamp, pb = 12, 6, 4
+    plain = bnr_amd.Chain(X, y, 5, nburn + nsamp, 77, 1)
+    plain.init_prior()
+    plain.run(2, nburn, nburn + nsamp)
+    ring = bnr_amd.Chain(X, y, 5, nsamp + pb, 77, 1)
+    ring.init_prior()
+    assert ring.run(2, nburn, nburn + nsamp, purge_burn=pb) == pb + nsamp + 1
+    o = bo.Oracle(X, y, 5, nsamp + pb, 77, pdf_mode=1)
+    o.init_prior()
+    o.run(2, nburn, nburn + nsamp, purge_burn=pb)
+    a, b = plain.fetch(), ring.fetch()
+    assert_tables_close(b, o.t, what="ring vs oracle ring")                  # incl. row 1 = last wrapped row
+    for k in bo.COLUMNS:
+        assert np.array_equal(a[k][nburn:nburn + nsamp], b[k][pb:pb + nsamp]), k
+    # a run split over two calls (first_index > 2) equals the single call bit for bit
+    two = bnr_amd.Chain(X, y, 5, nburn + nsamp, 77, 1)
+    two.init_prior()
+    assert two.run(2, nburn, 9) == 10
+    assert two.run(10, nburn, nburn + nsamp) == nburn + nsamp + 1
+    c = two.fetch()
+    for k in bo.COLUMNS:
+        assert np.allclose(a[k], c[k], rtol=1e-9, atol=1e-12), k
+    with pytest.raises(bnr_amd.BnrError):
+        two.run(2, 5, nburn + nsamp + 3)                                      # would write past the table
+    for ch in (plain, ring, two):
+        ch.close()
+
+
+def test_table_io_move_resize(gpu):
+    X, y, _ = bnr_amd.make_synthetic(30, 6, 3, seed=2)
+    ch = bnr_amd.Chain(X, y, 3, 10, 5, 1)
+    ch.init_prior()
+    ch.run(2, 10, 10)
+    full = ch.fetch()
+    # fetch into a larger host table at an offset, NULL columns skipped, dead columns untouched
+    host = bnr_amd.new_table(14, 6, 3, dead=True)
+    for k in ("Sigma_inv", "invC", "mu_t"):
+        host[k][:] = -7.0
+    ch.fetch(3, 8, host, host_row_offset=2)
+    for k in bo.COLUMNS:
+        assert np.array_equal(host[k][4:10], full[k][2:8]) and np.all(host[k][:4] == 0) and np.all(host[k][10:] == 0)
+    assert all(np.all(host[k] == -7.0) for k in ("Sigma_inv", "invC", "mu_t"))
+    # copy_table! semantics (utils.jl:72-84), overlapping forward move as the continuation loop does (gibbs.jl:991-993)
+    ch.move_rows(1, 5, 6)
+    moved = ch.fetch()
+    for k in bo.COLUMNS:
+        assert np.array_equal(moved[k][:6], full[k][4:10]) and np.array_equal(moved[k][6:], full[k][6:])
+    ch.resize(16)
+    assert ch.fetch(1, 10)["gamma"].shape[0] == 10 and np.array_equal(ch.fetch(1, 10)["S"], moved["S"])
+    # load a reference-layout table back and continue from it: same as the oracle continuing from the same rows
+    ch2 = bnr_amd.Chain(X, y, 3, 10, 5, 1)
+    ch2.load(full, 1, 4)
+    ch2.iter = 4
+    ch2.run(5, 10, 10)
+    again = ch2.fetch()
+    for k in bo.COLUMNS:
+        assert np.allclose(again[k], full[k], rtol=1e-9, atol=1e-12), k
+    ch.close()
+    ch2.close()
+
+
+def test_chains_on_one_gpu_are_independent_and_async(gpu, test1):
+    """Several chains share the GPU (run_async + sync): each equals the chain run alone; chain c uses stream seed+c."""
+    X, y = test1
+    alone = []
+    for c in (1, 2, 3):
+        ch = bnr_amd.Chain(X, y, 5, 25, 900, c)
+        ch.init_prior()
+        ch.run(2, 25, 25)
+        alone.append(ch.fetch())
+        ch.close()
+    chains = [bnr_amd.Chain(X, y, 5, 25, 900, c) for c in (1, 2, 3)]
+    for ch in chains:
+        ch.init_prior()
+    for ch in chains:
+        ch.run_async(2, 25, 25)
+    for ch in chains:
+        assert ch.sync() == 26
+    for ch, ref in zip(chains, alone):
+        got = ch.fetch()
+        for k in bo.COLUMNS:
+            assert np.array_equal(got[k], ref[k]), k
+        ch.close()
+    assert not np.array_equal(alone[0]["gamma"], alone[1]["gamma"])
+    o = bo.Oracle(X, y, 5, 25, 900, chain=2, pdf_mode=1)
+    o.init_prior()
+    o.run(2, 25, 25)
+    assert_tables_close(alone[1], o.t, what="chain 2")
+
+
+def test_generate_samples_end_to_end(gpu, test1, tmp_path):
+    """generate_samples! / Fit! drop-in (gibbs.jl:725-751, 897-1020): Results layout, Rhat over 2 chains, top-up loop."""
+    X, y = test1
+    keep = []
+    res = bnr_amd.generate_samples(X, y, 5, nburn=40, nsamp=30, maxburn=40, psrf_cutoff=1.2, x_transform=False,
+                                   suppress_timer=True, num_chains=2, seed=1234, _keep=keep)
+    assert res.burn_in == 40 and res.sampled == 30
+    assert res.state["gamma"].shape == (70, 190, 1) and res.state["u"].shape == (70, 5, 19) and res.state["pi"].shape == (70, 5, 3)
+    assert set(res.state) == set(bnr_amd._capi.TABLE_COLUMNS + bnr_amd._capi.DEAD_COLUMNS)
+    cs = keep[0]
+    tabs = [cs.chains[c].fetch() for c in (1, 2)]
+    both_g = np.stack([t["gamma"][40:70, :, 0] for t in tabs], axis=2)
+    both_x = np.stack([t["xi"][40:70, :, 0] for t in tabs], axis=2)
+    assert np.allclose(res.rhatgamma, bo.rhat(both_g), rtol=1e-10) and np.allclose(res.rhatxi, bo.rhat(both_x), rtol=1e-10)
+    assert np.array_equal(res.state["gamma"], tabs[0]["gamma"])               # only chain 1's trace is returned (gibbs.jl:788)
+    o = bo.Oracle(X, y, 5, 70, 1234, chain=1, pdf_mode=1)
+    o.init_prior()
+    o.run(2, 40, 70)
+    assert_tables_close(tabs[0], o.t, what="generate_samples chain 1")
+    cs.close()
+    # top-up loop: an impossible cutoff forces exactly one extra round of nburn samples (maxburn = nburn + 1)
+    keep = []
+    res2 = bnr_amd.generate_samples(X, y, 5, nburn=20, nsamp=10, maxburn=21, psrf_cutoff=0.5, x_transform=False,
+                                    suppress_timer=True, num_chains=2, seed=5, _keep=keep)
+    o = bo.Oracle(X, y, 5, 30, 5, chain=1, pdf_mode=1)
+    o.init_prior()
+    o.run(2, 20, 30)
+    for i in range(10):                                                       # copy_table! loop, gibbs.jl:991-993
+        for k in bo.COLUMNS:
+            o.t[k][i] = o.t[k][20 + i]
+    o.run(11, 20, 30)                                                         # run!(…, num2move+1, nburn-nsamp+num2move, num2move+nburn)
+    assert_tables_close(keep[0].chains[1].fetch(), o.t, what="top-up round")
+    keep[0].close()
+    # Fit! writes parameters.log and dispatches on mingen/maxgen (doubling scheme)
+    log = tmp_path / "parameters.log"
+    r3 = bnr_amd.Fit(X, y, 5, mingen=20, maxgen=40, psrf_cutoff=0.5, x_transform=False, suppress_timer=True,
+                     num_chains=2, seed=9, filename=str(log))
+    txt = log.read_text()
+    assert "BayesianNetworkRegression.jl Fit! function" in txt and "seed=9" in txt and "mingen=20, maxgen=40" in txt
+    assert r3.burn_in == 10 and r3.sampled == 20 and r3.state["gamma"].shape[0] == 30
+
+
+def test_bad_arguments_are_reported(gpu):
+    X, y, _ = bnr_amd.make_synthetic(8, 4, 2, seed=1)
+    with pytest.raises(bnr_amd.BnrError) as e:
+        bnr_amd.Chain(X, y, 40, 4, 1, 1)
+    assert e.value.code == 1
+    with pytest.raises(bnr_amd.BnrError):
+        bnr_amd.Chain(X, y, 2, 4, 1, 1, device=99)
+    ch = bnr_amd.Chain(X, y, 2, 4, 1, 1)
+    ch.init_prior()
+    with pytest.raises(bnr_amd.BnrError):
+        ch.update("gamma", 1, 2)                                              # row 1 has no predecessor
+    with pytest.raises(bnr_amd.BnrError):
+        ch.fetch(0, 3)
+    ch.close()
+
+
+def test_headline_size_properties(gpu):
+    """n=500, V=100 (q=5050), R=7 (BASELINE.json configs[2]): size-independent properties of the HIP path.
+      * determinism: two runs of the same seed are bitwise equal;
+      * the carried n-vector bookkeeping (X gamma from the Gram, no third pass over X) agrees with a recomputation
+        from scratch: a run split in two calls (second call re-derives the carried sums by an explicit X*gamma pass)
+        equals the single-call run to 1e-9;
+      * discrete columns take only their legal values, S > 0, pi rows sum to 1, M symmetric positive definite;
+      * the first rows equal the oracle's."""
+    X, y, _ = bnr_amd.make_synthetic(500, 100, 7, seed=20240501)
+    tot = 40
+    a = bnr_amd.Chain(X, y, 7, tot, 20240501, 1)
+    a.init_prior()
+    a.run(2, tot, tot)
+    A = a.fetch()
+    b = bnr_amd.Chain(X, y, 7, tot, 20240501, 1)
+    b.init_prior()
+    b.run(2, tot, 17)
+    b.run(18, tot, tot)
+    B = b.fetch()
+    c = bnr_amd.Chain(X, y, 7, tot, 20240501, 1)
+    c.init_prior()
+    c.run(2, tot, tot)
+    Cc = c.fetch()
+    for k in bo.COLUMNS:
+        assert np.array_equal(A[k], Cc[k]), k
+        assert np.allclose(A[k], B[k], rtol=1e-7, atol=1e-10), k
+        assert np.all(np.isfinite(A[k])), k
+    assert set(np.unique(A["xi"])) <= {0.0, 1.0} and set(np.unique(A["lam"])) <= {0.0, 1.0, -1.0}
+    assert np.all(A["S"] > 0) and np.all(A["tau2"] > 0) and np.all(A["theta"] > 0)
+    assert np.allclose(A["pi"].sum(axis=2), 1.0)
+    for i in range(tot):
+        M = A["M"][i]
+        assert np.allclose(M, M.T, rtol=1e-10) and np.all(np.linalg.eigvalsh(M) > 0)
+        assert np.all(A["u"][i][:, A["xi"][i, :, 0] == 0] == 0)
+    o = bo.Oracle(X, y, 7, 4, 20240501, chain=1, pdf_mode=1)
+    o.init_prior()
+    o.run(2, 4, 4)
+    assert_tables_close(A, o.t, rows_got=slice(0, 4), what="headline first rows")
+    for ch in (a, b, c):
+        ch.close()

@@ -1,0 +1,184 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol of include/bnr_hip.h,
+its host copies of the draw-site primitives equal the oracle's bit for bit, the split-Rhat finish equals rhat(),
+the reference-interface helpers behave as the reference's, and the multi-rank Rhat exchange works over gloo.
+No compute call is made (there is no GPU here); the GPU path is covered by the -m gpu tests."""
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import bnr_amd
+from oracle import bnr_oracle as bo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "bnr_hip.h")).read()
+    declared = set(re.findall(r"\b(bnr_[a-zA-Z0-9_]+)\s*\(", hdr)) - {"bnr_progress_cb"}
+    assert len(declared) >= 35
+    L = bnr_amd.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), "libbnr_hip.so does not export %s" % name
+    assert declared == set(bnr_amd.EXPORTS), declared ^ set(bnr_amd.EXPORTS)
+    assert L.bnr_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU the product must fail loudly (status BNR_ERR_HIP), never compute on the CPU."""
+    try:
+        ndev = bnr_amd.device_count()
+    except bnr_amd.BnrError as e:
+        assert e.code == 2
+        ndev = 0
+    if ndev == 0:
+        X, y, _ = bnr_amd.make_synthetic(8, 4, 2, seed=1)
+        with pytest.raises(bnr_amd.BnrError):
+            bnr_amd.Chain(X, y, 2, 4, 1, 1)
+        with pytest.raises(bnr_amd.BnrError):
+            bnr_amd.generate_samples(X, y, 2, nburn=2, nsamp=2, x_transform=False, num_chains=1, seed=1, suppress_timer=True)
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "bayesiannetworkregression.jl_amd")
+    for dirpath, _d, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("not the oracle", ""), "%s mentions the oracle" % f
+
+
+def test_host_rng_equals_oracle_bitwise():
+    import ctypes as C
+    L = bnr_amd.lib()
+    rng = np.random.default_rng(5)
+    out = (C.c_uint32 * 4)()
+    for _ in range(50):
+        c = [int(v) for v in rng.integers(0, 2**32, 4)]
+        k = [int(v) for v in rng.integers(0, 2**32, 2)]
+        L.bnr_host_philox((C.c_uint32 * 4)(*c), (C.c_uint32 * 2)(*k), out)
+        assert list(out) == bo.philox(c, k)
+    d = np.load(os.path.join(G, "test1_xy.npz"))
+    o = bo.Oracle(d["X"], d["y"], 5, 4, 1000, chain=1)
+    seed = 1001
+    u2 = (C.c_double * 2)()
+    for e in range(300):
+        L.bnr_host_uniform2(seed, 7, 21, e, 3, u2)
+        assert (u2[0], u2[1]) == bo.uniform2(seed, 7, 21, e, 3)
+        assert 0.0 < u2[0] < 1.0 and 0.0 < u2[1] < 1.0
+        assert L.bnr_host_normal(seed, 5, 19, e, 0) == bo.normal(seed, 5, 19, e, 0)
+        for sh in (0.5, 1.0, 2.5, 130.5):
+            assert L.bnr_host_gamma(seed, sh, 5, 23, e) == o.gamma_draw(sh, 5, 23, e)
+    for e in range(2000):
+        chi, psi = 10 ** rng.uniform(-7, 2), 10 ** rng.uniform(-2, 1)
+        assert L.bnr_host_gig(seed, 0.5, chi, psi, 5, e) == o.sample_gig(0.5, chi, psi, 5, e)
+    assert sum(o.o.gig_branch[:3]) == 2000 and min(o.o.gig_branch[:3]) > 50      # all three branches exercised
+    for V in (2, 5, 19):
+        e = 0
+        for k in range(V):
+            for l in range(k, V):
+                assert L.bnr_host_edge_index(V, l, k) == e == L.bnr_host_edge_index(V, k, l)
+                e += 1
+
+
+def _stats_from_table(g, xi, first, nsamp):
+    """numpy restatement of bnr_chain_rhat_stats' message for one chain."""
+    par = np.concatenate([g[first:first + nsamp, :, 0], xi[first:first + nsamp, :, 0]], axis=1)
+    h = nsamp // 2
+    a, b = par[:h], par[nsamp - h:]
+    return np.concatenate([a.mean(0), a.var(0, ddof=1), b.mean(0), b.var(0, ddof=1)])
+
+
+@pytest.mark.parametrize("name", ["res", "res2"])
+def test_rhat_from_stats_known_answer(name):
+    g = dict(np.load(os.path.join(G, "golden_%s.npz" % name)))
+    b, s = int(g["burn_in"]), int(g["sampled"])
+    st = _stats_from_table(g["gamma"], g["xi"], b, s)[None, :]
+    r = bnr_amd.rhat_from_stats(st, s)
+    q = g["gamma"].shape[1]
+    assert np.allclose(r[:q], g["rhat_gamma"], rtol=1e-12) and np.allclose(r[q:], g["rhat_xi"], rtol=1e-12)
+
+
+def test_rhat_from_stats_multichain_equals_oracle_rhat():
+    rng = np.random.default_rng(2)
+    nsamp, q, V, C = 41, 6, 3, 3
+    gam = rng.standard_normal((C, nsamp, q, 1)) + np.arange(C)[:, None, None, None] * 0.3
+    xi = (rng.random((C, nsamp, V, 1)) < 0.4).astype(float)
+    xi[:, :, 0, :] = 1.0                                     # constant parameter -> Rhat = 1
+    st = np.stack([_stats_from_table(gam[c], xi[c], 0, nsamp) for c in range(C)])
+    r = bnr_amd.rhat_from_stats(st, nsamp)
+    ref_g = bo.rhat(np.transpose(gam[:, :, :, 0], (1, 2, 0)))
+    ref_x = bo.rhat(np.transpose(xi[:, :, :, 0], (1, 2, 0)))
+    assert np.allclose(r[:q], ref_g, rtol=1e-12) and np.allclose(r[q:], ref_x, rtol=1e-12)
+    assert r[q] == 1.0
+
+
+def test_lower_triangle_and_setup_X():
+    A = np.arange(16.0).reshape(4, 4)
+    v = bnr_amd.lower_triangle(A)                            # reads matrix[j,i], j >= i  (utils.jl:50-55)
+    assert list(v) == [0, 4, 8, 12, 5, 9, 13, 10, 14, 15]
+    B = bnr_amd.create_lower_tri(v, 4)
+    assert np.array_equal(B, np.tril(A))
+    mats = [np.tril(np.random.default_rng(i).random((5, 5))) for i in range(3)]
+    Xn, V, q = bnr_amd.setup_X(mats, True)
+    assert (V, q) == (5, 15) and Xn.shape == (3, 15) and np.array_equal(Xn[1], bnr_amd.lower_triangle(mats[1]))
+    Xb = (np.random.default_rng(0).random((6, 10)) < 0.5)   # Bool input is converted to Float64 (toy test uses Bool X)
+    Xn, V, q = bnr_amd.setup_X(Xb, False)
+    assert (V, q) == (4, 10) and Xn.dtype == np.float64
+    ex = np.load(os.path.join(G, "examples_xy.npz"))
+    Xn, V, q = bnr_amd.setup_X(ex["X"], False)
+    assert (V, q) == (30, 465)
+
+
+def test_synthetic_generator_is_deterministic():
+    X1, y1, t1 = bnr_amd.make_synthetic(20, 6, 3, seed=3)
+    X2, y2, t2 = bnr_amd.make_synthetic(20, 6, 3, seed=3)
+    assert np.array_equal(X1, X2) and np.array_equal(y1, y2) and X1.shape == (20, 21)
+    assert 0.3 < (X1 == 0).mean() < 0.7 and X1.min() >= 0
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+import bnr_amd
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+num_chains, width = int(sys.argv[4]), 4 * 9
+ids = bnr_amd.local_chain_ids(num_chains)
+assert ids == [c for c in range(1, num_chains + 1) if (c - 1) % world == rank], ids
+rng = lambda c: np.random.default_rng(100 + c).random(width)
+local = {{c: rng(c) for c in ids}}
+allst = bnr_amd.allgather_stats(local, num_chains)
+ref = np.stack([rng(c) for c in range(1, num_chains + 1)])
+assert np.array_equal(allst, ref)
+r = bnr_amd.rhat_from_stats(allst, 20)
+np.save(sys.argv[5] + ".%d.npy" % rank, r)
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("num_chains", [2, 3, 1])
+def test_rhat_exchange_two_ranks_gloo(tmp_path, num_chains):
+    """World size 2 over gloo: chains sharded round-robin, per-chain messages all-gathered, every rank finishes the
+    same Rhat (the RCCL path of bench.py / generate_samples uses the same code with backend nccl)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    out = str(tmp_path / "rhat")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(port), str(num_chains), out]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=180) == 0
+    r0, r1 = np.load(out + ".0.npy"), np.load(out + ".1.npy")
+    assert np.array_equal(r0, r1)
+    ref = np.stack([np.random.default_rng(100 + c).random(36) for c in range(1, num_chains + 1)])
+    assert np.allclose(r0, bnr_amd.rhat_from_stats(ref, 20))
