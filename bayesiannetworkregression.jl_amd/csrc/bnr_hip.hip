@@ -32,8 +32,11 @@ struct bnr_chain {
     int next_row = 0;            // 1-based j the next run call would write
     bool pending = false;
     long long *counters_host = nullptr;
+    int *pbase_dev = nullptr;
     // options
-    int use_graph = 0;
+    int use_graph = 1, graph_k = 8;
+    hipGraphExec_t gexec = nullptr;
+    hipGraph_t graph = nullptr;
     // profiling
     int profiling = 0;
     std::vector<hipEvent_t> ev;  // pairs around k_gram, plus [begin,end] of the run
@@ -169,17 +172,20 @@ int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const dou
     TRY(dev_alloc(c, &d.PG, (size_t)d.nblk_x * d.n_pad));
     TRY(dev_alloc(c, &d.Gpart, (size_t)d.ksplit * ntl * BNR_GT * BNR_GT));
     TRY(dev_alloc(c, &d.G, (size_t)d.n_pad * d.n_pad));
-    TRY(dev_alloc(c, &d.invD, (size_t)(d.n_pad / BNR_NB) * BNR_NB * BNR_NB));
+    TRY(dev_alloc(c, &d.Winv, (size_t)d.n_pad * d.n_pad));
     TRY(dev_alloc(c, &d.a3, d.n_pad));
     TRY(dev_alloc(c, &d.xw, d.n_pad));
     TRY(dev_alloc(c, &d.a4, d.n_pad));
     TRY(dev_alloc(c, &d.res, d.n_pad));
     TRY(dev_alloc(c, &d.xg, d.n_pad));
+    TRY(dev_alloc(c, &d.bw, d.n_pad));
     TRY(dev_alloc(c, &d.scal, 16));
     TRY(dev_alloc(c, &d.Psum, (size_t)d.nblk_bp * (1 + 3 * R)));
     TRY(dev_alloc(c, &d.counters, 8));
-    c->plan_cap = 4096;
+    c->plan_cap = 1 << 16;
     TRY(dev_alloc(c, &c->plan_dev, c->plan_cap));
+    TRY(dev_alloc(c, &c->pbase_dev, 4));
+    d.pbase = c->pbase_dev;
     if (hipHostMalloc((void **)&c->plan_pin, sizeof(bnr_plan_entry) * c->plan_cap) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipHostMalloc failed"); }
     if (hipHostMalloc((void **)&c->counters_host, sizeof(long long) * 8) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipHostMalloc failed"); }
     d.plan = c->plan_dev;
@@ -188,11 +194,18 @@ int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const dou
     return BNR_OK;
 }
 
+static void drop_graph(bnr_chain *c)
+{
+    if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+}
+
 int bnr_chain_destroy(bnr_chain *c)
 {
     if (!c) return BNR_OK;
     hipSetDevice(c->device);
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+    drop_graph(c);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     for (void *p : c->allocs) hipFree(p);
     if (c->d.trace) hipFree(c->d.trace);
@@ -217,11 +230,13 @@ static int ensure_plan(bnr_chain *c, int count)
     c->allocs.push_back(nd);
     c->plan_dev = nd; c->plan_pin = np; c->plan_cap = cap;
     c->d.plan = nd;
+    drop_graph(c);                       // kernel arguments baked into the captured graph changed
     return BNR_OK;
 }
 static int upload_plan(bnr_chain *c, int count)
 {
     HIPCHK(hipMemcpyAsync(c->plan_dev, c->plan_pin, sizeof(bnr_plan_entry) * count, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->pbase_dev, 0, sizeof(int), c->stream));
     return BNR_OK;
 }
 static int check_launch(const char *what)
@@ -244,14 +259,16 @@ static void launch_factor(bnr_chain *c, int s, bool timed)
         c->ev.push_back(e0); c->ev.push_back(e1);
         hipEventRecord(e0, c->stream);
     }
-    hipLaunchKernelGGL(k_gram, dim3(ntl, d.ksplit), dim3(256), 0, c->stream, c->d, s);
+    hipLaunchKernelGGL(k_gram, dim3(ntl, d.ksplit), dim3(1024), 0, c->stream, c->d, s);
     if (timed) hipEventRecord(e1, c->stream);
-    hipLaunchKernelGGL(k_gram_reduce, dim3(ntl), dim3(256), 0, c->stream, c->d);
-    const int nb = d.n_pad / BNR_NB;
-    for (int p = 0; p < nb; ++p) hipLaunchKernelGGL(k_chol_panel, dim3(nb - p), dim3(256), 0, c->stream, c->d, p);
+    hipLaunchKernelGGL(k_gram_reduce, dim3(ntl, 4), dim3(256), 0, c->stream, c->d);
+    hipLaunchKernelGGL(k_rhs, dim3(d.n_pad / 64), dim3(256), 0, c->stream, c->d, s);
+    const int nbk = d.n_pad / BNR_NB;
+    for (int p = 0; p < nbk; ++p)
+        hipLaunchKernelGGL(k_chol_step, dim3(bnr_chol_npanel(nbk, p) + bnr_chol_ntile(nbk, p)), dim3(256), 0, c->stream, c->d, p);
 }
 static void launch_solve(bnr_chain *c, int s)
-{ hipLaunchKernelGGL(k_solve, dim3(1), dim3(1024), (c->d.n_pad + BNR_NB) * sizeof(double), c->stream, c->d, s); }
+{ (void)s; hipLaunchKernelGGL(k_solve_gemv, dim3(c->d.n_pad / 4), dim3(256), 0, c->stream, c->d); }
 static void launch_backproj(bnr_chain *c, int s, int flags)
 { hipLaunchKernelGGL(k_backproj, dim3(c->d.nblk_bp), dim3(256), (c->d.n_pad + 64) * sizeof(double), c->stream, c->d, s, flags); }
 static void launch_tail(bnr_chain *c, int s, int mask, int xg_src)
@@ -266,6 +283,31 @@ static void launch_sweep(bnr_chain *c, int s)
     launch_solve(c, s);
     launch_backproj(c, s, 7);
     launch_tail(c, s, 255, 0);
+}
+
+// Enqueue `count` consecutive sweeps starting at the current plan base.  Full batches of graph_k sweeps replay one
+// captured hipGraph (kernel boundaries without host launch cost); the remainder is launched eagerly.
+static int launch_range(bnr_chain *c, int count)
+{
+    int done = 0;
+    if (c->use_graph && !c->profiling && c->graph_k > 0) {
+        const int K = c->graph_k;
+        while (count - done >= K) {
+            if (!c->gexec) {
+                HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+                for (int s = 0; s < K; ++s) launch_sweep(c, s);
+                hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, c->stream, c->pbase_dev, K);
+                HIPCHK(hipStreamEndCapture(c->stream, &c->graph));
+                HIPCHK(hipGraphInstantiate(&c->gexec, c->graph, nullptr, nullptr, 0));
+            }
+            HIPCHK(hipGraphLaunch(c->gexec, c->stream));
+            done += K;
+        }
+    }
+    const int r = count - done;
+    for (int s = 0; s < r; ++s) launch_sweep(c, s);
+    if (r > 0) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, c->stream, c->pbase_dev, r);
+    return BNR_OK;
 }
 
 // (re)compute the carried sums rr, sig_q from 0-based row r (needed after init, load, hooks)
@@ -348,13 +390,23 @@ int bnr_chain_run(bnr_chain *c, int32_t first_index, int32_t nburn, int32_t tota
     c->ev.clear();
     hipEvent_t r0 = nullptr, r1 = nullptr;
     if (c->profiling) { hipEventCreate(&r0); hipEventCreate(&r1); hipEventRecord(r0, c->stream); }
-    for (int s = 0; s < count; ++s) {
-        launch_sweep(c, s);
-        int i = first_index + s;
-        if (cb && prog_freq > 0 && (i % prog_freq == 0)) {          // gibbs.jl:854-856
-            HIPCHK(hipStreamSynchronize(c->stream));
-            cb(user, (int64_t)(s + 1));
+    if (cb && prog_freq > 0) {
+        int s = 0;
+        while (s < count) {                                          // tick every prog_freq iterations (gibbs.jl:854-856)
+            int i = first_index + s;
+            int next_tick = ((i + prog_freq - 1) / prog_freq) * prog_freq;
+            int seg = std::min(count - s, next_tick - i + 1);
+            rc = launch_range(c, seg);
+            if (rc) return rc;
+            s += seg;
+            if ((first_index + s - 1) % prog_freq == 0) {
+                HIPCHK(hipStreamSynchronize(c->stream));
+                cb(user, (int64_t)s);
+            }
         }
+    } else {
+        rc = launch_range(c, count);
+        if (rc) return rc;
     }
     if (c->profiling) hipEventRecord(r1, c->stream);
     rc = check_launch("sweep");
@@ -384,8 +436,9 @@ int bnr_chain_run_async(bnr_chain *c, int32_t first_index, int32_t nburn, int32_
     const int count = total - first_index + 1;
     int saved = c->profiling;
     c->profiling = 0;
-    for (int s = 0; s < count; ++s) launch_sweep(c, s);
+    rc = launch_range(c, count);
     c->profiling = saved;
+    if (rc) return rc;
     c->pending = true;
     if (count > 0) c->carried_row = -2 - c->plan_pin[count - 1].row;    // becomes valid at sync
     return check_launch("sweep");
@@ -630,6 +683,7 @@ int bnr_chain_resize(bnr_chain *c, int32_t new_tot)
     HIPCHK(hipMemcpy(nt, old, keep, hipMemcpyDeviceToDevice));
     hipFree(old);
     d.trace = nt; d.tot = new_tot;
+    drop_graph(c);
     return BNR_OK;
 }
 
@@ -709,6 +763,7 @@ int bnr_chain_set_option(bnr_chain *c, const char *name, int64_t value)
 {
     if (!c || !name) return fail(BNR_ERR_BAD_ARG, "NULL argument");
     if (!strcmp(name, "graph")) { c->use_graph = (int)value; return BNR_OK; }
+    if (!strcmp(name, "graph_k")) { if (value < 1 || value > 256) return fail(BNR_ERR_BAD_ARG, "graph_k out of range"); c->graph_k = (int)value; drop_graph(c); return BNR_OK; }
     return fail(BNR_ERR_BAD_ARG, std::string("unknown option ") + name);
 }
 

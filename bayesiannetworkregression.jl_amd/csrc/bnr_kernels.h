@@ -39,14 +39,15 @@ struct bnr_dev {
     // state
     double *trace;
     const bnr_plan_entry *plan;
+    const int *pbase;            // plan[pbase[0] + s] is the entry of slot s (lets a captured graph be replayed)
     // work
     double *Wbuf, *sz;           // q_pad each
     double *PW, *PA;             // nblk_x x n_pad GEMV partials (X W, X sz)
     double *PG;                  // nblk_x x n_pad GEMV partials (X gamma, refresh path)
     int nblk_x, chunk_x;
-    double *Gpart, *G, *invD;    // Gram partial tiles, G (n_pad x n_pad col-major), inverse diagonal blocks of L
+    double *Gpart, *G, *Winv;    // Gram partial tiles, G (n_pad x n_pad col-major; holds L after the factorization), Winv = L^-1
     int ksplit, ntile;           // ntile = n_pad/64
-    double *a3, *xw, *a4, *res, *xg;   // n_pad each
+    double *a3, *xw, *a4, *res, *xg, *bw;   // n_pad each (bw: rhs b, overwritten by w = L^-1 b)
     double *scal;                // [0]=rr (sum res^2), [1]=sig_q (sum (g^2/2)/S), [2]=tau (sqrt tau2 of current row)
     double *Psum;                // nblk_bp x (1+3R) partial sums from k_backproj
     int nblk_bp, chunk_bp;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(64) void k_node(bnr_dev cd, int s, int mode)
     __shared__ double sM[BNR_RMAX * BNR_RMAX], sMinv[BNR_RMAX * BNR_RMAX], sS[BNR_RMAX * BNR_RMAX], sL[BNR_RMAX * BNR_RMAX];
     __shared__ double slam[BNR_RMAX], sc[BNR_RMAX];
     const int lane = threadIdx.x, k = blockIdx.x, V = cd.V, R = cd.R;
-    const bnr_plan_entry P = cd.plan[s];
+    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     double *row = cd.trace + (size_t)P.row * cd.rowlen;
     const double *prev = cd.trace + (size_t)P.prev * cd.rowlen;
     int cap = 0;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void k_xpass(bnr_dev cd, int s, int which)
 {
     extern __shared__ double sh[];
     double *sW = sh, *sZ = sh + cd.chunk_x, *sG = sh + 2 * cd.chunk_x;
-    const bnr_plan_entry P = cd.plan[s];
+    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     const double *row = cd.trace + (size_t)P.row * cd.rowlen;
     const double *prev = cd.trace + (size_t)P.prev * cd.rowlen;
     const int R = cd.R;
@@ -304,233 +305,336 @@ __global__ __launch_bounds__(256) void k_xpass(bnr_dev cd, int s, int which)
 
 // ===================================================================================== k_gram
 // G = X diag(S_prev) X'  (the n x n matrix of gibbs.jl:434 without the identity; tau cancels: Xt tau2 D Xt' = X D X').
-// v_mfma_f64_16x16x4_f64: A[i][k] = X[i0+i, e0+k] (lane l: i = l&15, k = l>>4), B[k][j] = S_e X[j0+j, e0+k],
-// C[i][j]: lane l holds rows (l>>4) + 4*reg, column l&15.
-// Workgroup = 4 waves (2x2) -> 64x64 tile of the LOWER triangle; blockIdx.y = K slice.  Each wave: 32x32 = 2x2 MFMA tiles.
-// Output: partial tile stored [i][j] row-major (coalesced): Gpart[(ks*ntl + t)][i*64 + j].
+// v_mfma_f64_16x16x4_f64, D = A*B + C with A[m][k] (lane l: m = l&15, k = l>>4), B[k][n] (k = l>>4, n = l&15),
+// C[m][n]: lane l holds rows m = (l>>4) + 4*reg, column n = l&15.
+// Here m indexes the tile's COLUMN (j) and n its ROW (i): A = X[j-rows], B = S_e X[i-rows], so that a lane's results are
+// consecutive in i and the tile is written column-major (i fastest) with coalesced 128-byte segments.
+// Workgroup = 1024 threads = 16 waves on one 64x64 tile of the LOWER triangle: 4 K-groups x (2x2 waves of 32x32).
+// Measured issue rate of the f64 MFMA rises with waves per SIMD (1 wave: 139, 2: 103, 4: 92 cycles/MFMA;
+// profiles/round1_mfma_f64_peak.txt), hence 4 waves per SIMD and the in-workgroup K split, reduced through LDS.
+// blockIdx.y = K slice across workgroups (split-K partials, summed by k_gram_reduce).
 typedef double bnr_d4 __attribute__((ext_vector_type(4)));
+#define BNR_GRAM_KG 4
 
-__global__ __launch_bounds__(256) void k_gram(bnr_dev cd, int s)
+__global__ __launch_bounds__(1024) void k_gram(bnr_dev cd, int s)
 {
-    const bnr_plan_entry P = cd.plan[s];
+    __shared__ double sred[BNR_GRAM_KG * BNR_GT * BNR_GT];     // 128 KiB: one 64x64 tile per K-group
+    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     const double *Sp = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
-    // tile index -> (ti >= tj)
     int t = blockIdx.x, ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     int tj = t - ti * (ti + 1) / 2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wi = wave >> 1, wj = wave & 1;
+    const int kg = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
     const int i0 = ti * BNR_GT + wi * 32, j0 = tj * BNR_GT + wj * 32;
     const int ks = blockIdx.y;
-    const int kchunk = cd.q_pad / cd.ksplit;          // multiple of 4 (host guarantees)
-    const int eb = ks * kchunk, ee = eb + kchunk;
+    const int kchunk = cd.q_pad / cd.ksplit;          // multiple of 16 (host guarantees)
+    const int ksub = kchunk / BNR_GRAM_KG;            // multiple of 4
+    const int eb = ks * kchunk + kg * ksub, ee = eb + ksub;
     const size_t ld = cd.n_pad;
     const int li = lane & 15, lk = lane >> 4;
-    const double *xa = cd.X + (size_t)(i0 + li) + (size_t)(eb + lk) * ld;
-    const double *xb = cd.X + (size_t)(j0 + li) + (size_t)(eb + lk) * ld;
-    bnr_d4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
+    const double *xi = cd.X + (size_t)(i0 + li) + (size_t)(eb + lk) * ld;
+    const double *xj = cd.X + (size_t)(j0 + li) + (size_t)(eb + lk) * ld;
+    bnr_d4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};   // c[jt][it]
 #pragma unroll 4
     for (int e = eb; e < ee; e += 4) {
         int ecol = e + lk;
         double sv = (ecol < cd.q) ? Sp[ecol] : 0.0;
-        double a0 = xa[0], a1 = xa[16];
-        double b0 = xb[0] * sv, b1 = xb[16] * sv;
+        double a0 = xj[0], a1 = xj[16];
+        double b0 = xi[0] * sv, b1 = xi[16] * sv;
         c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
         c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
         c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
         c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
-        xa += 4 * ld; xb += 4 * ld;
+        xi += 4 * ld; xj += 4 * ld;
     }
-    double *out = cd.Gpart + ((size_t)ks * (cd.ntile * (cd.ntile + 1) / 2) + t) * (BNR_GT * BNR_GT);
-    const int rbase = wi * 32 + (lane >> 4), cbase = wj * 32 + (lane & 15);
+    // tile element (i,j) lives at [j*64 + i]; this lane: j = wj*32 + jt*16 + (lane>>4) + 4 r, i = wi*32 + it*16 + (lane&15)
+    double *mine = sred + (size_t)kg * (BNR_GT * BNR_GT);
+    const int jb = wj * 32 + (lane >> 4), ib = wi * 32 + (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        out[(rbase + 4 * r) * BNR_GT + cbase] = c00[r];
-        out[(rbase + 4 * r) * BNR_GT + cbase + 16] = c01[r];
-        out[(rbase + 16 + 4 * r) * BNR_GT + cbase] = c10[r];
-        out[(rbase + 16 + 4 * r) * BNR_GT + cbase + 16] = c11[r];
+        mine[(jb + 4 * r) * BNR_GT + ib] = c00[r];
+        mine[(jb + 4 * r) * BNR_GT + ib + 16] = c01[r];
+        mine[(jb + 16 + 4 * r) * BNR_GT + ib] = c10[r];
+        mine[(jb + 16 + 4 * r) * BNR_GT + ib + 16] = c11[r];
     }
+    __syncthreads();
+    double *out = cd.Gpart + ((size_t)ks * (cd.ntile * (cd.ntile + 1) / 2) + t) * (BNR_GT * BNR_GT);
+#pragma unroll
+    for (int idx = threadIdx.x; idx < BNR_GT * BNR_GT; idx += 1024)
+        out[idx] = (sred[idx] + sred[BNR_GT * BNR_GT + idx]) + (sred[2 * BNR_GT * BNR_GT + idx] + sred[3 * BNR_GT * BNR_GT + idx]);
 }
 
-// G = sum_ks partial + I, written as the full symmetric n_pad x n_pad column-major matrix.
-// grid = number of lower tiles, 256 threads.
+// G = sum_ks partial + I, lower tiles of the n_pad x n_pad column-major matrix.  grid = (lower tiles, 4), 256 threads.
 __global__ __launch_bounds__(256) void k_gram_reduce(bnr_dev cd)
 {
     int t = blockIdx.x, ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     int tj = t - ti * (ti + 1) / 2;
     const int ntl = cd.ntile * (cd.ntile + 1) / 2;
-    const size_t ld = cd.n_pad;
-    for (int idx = threadIdx.x; idx < BNR_GT * BNR_GT; idx += blockDim.x) {
+    const size_t ld = cd.n_pad, tsz = BNR_GT * BNR_GT;
+    const int idx0 = blockIdx.y * (BNR_GT * BNR_GT / 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        int idx = idx0 + u * 256 + threadIdx.x;
         double sacc = 0.0;
-        for (int ks = 0; ks < cd.ksplit; ++ks) sacc += cd.Gpart[((size_t)ks * ntl + t) * (BNR_GT * BNR_GT) + idx];
-        int i = ti * BNR_GT + idx / BNR_GT, j = tj * BNR_GT + idx % BNR_GT;   // element (i,j), i-tile >= j-tile
-        if (i < j) continue;                  // diagonal tiles: keep the lower half only (one writer per element)
+        for (int ks = 0; ks < cd.ksplit; ++ks) sacc += cd.Gpart[((size_t)ks * ntl + t) * tsz + idx];
+        int i = ti * BNR_GT + idx % BNR_GT, j = tj * BNR_GT + idx / BNR_GT;
         if (i == j) sacc += 1.0;
-        cd.G[(size_t)j + ld * i] = sacc;      // (j,i): coalesced (idx%64 fastest)
-        cd.G[(size_t)i + ld * j] = sacc;      // (i,j)
+        cd.G[(size_t)i + ld * j] = sacc;
     }
 }
 
-// ===================================================================================== k_chol_panel
-// Left-looking blocked Cholesky of G (lower), one launch per block column p (NB = 32).
-// grid = nb - p blocks (block b handles block row i = p + b), 256 threads.
-//   D = G[p,p] - sum_{k<p} L[p,k] L[p,k]'   (every block, redundantly)   -> L[p,p] = chol(D), invD[p] = L[p,p]^-1
-//   B = G[i,p] - sum_{k<p} L[i,k] L[p,k]'                                -> L[i,p] = B L[p,p]^-T
-__global__ __launch_bounds__(256) void k_chol_panel(bnr_dev cd, int p)
+// ===================================================================================== blocked Cholesky + solve
+// (G + I) a4 = b,  b = a1 - a3  (gibbs.jl:434; the reference's generic `\` is an LU solve of this SPD system).
+// Right-looking blocked Cholesky, NB = 32, ONE launch per panel with lookahead 1 (k_chol_step(p), p = 0..nbk-1).
+// The matrix is extended by two kinds of extra rows that ride through the same sweeps:
+//     [ G + I ]  block rows 0..nbk-1        -> L
+//     [  b'   ]  one row                    -> w' = (L^-1 b)'          (the forward substitution, for free)
+//     [   I   ]  block rows 0..nbk-1        -> L^-T                    (so the back substitution becomes one GEMV)
+//   role A (panel workgroups): a block row first applies panel p-1's update to its blocks (p,p) and (i,p), then one
+//       wavefront sweeps the 64 x 32 register-resident panel [A_pp ; A_ip] column by column: pivot broadcast by
+//       v_readlane, rsqrt by v_rsq_f64 + 2 Newton steps, rank-1 updates by v_fma_f64 with the broadcast in SGPRs.
+//       Lanes 0-31 redo the diagonal block in every workgroup (no cross-workgroup hand-off inside a launch).
+//   role B (update workgroups): apply panel p-1's update to every block (.,j), j >= p+1.
+// Identity block row r is zero left of column block r, so it takes part from panel r on.  L^-T is stored transposed,
+// Winv = L^-1 column-major, so that row r of L^-T is the contiguous column r of Winv.
+// k_solve_gemv: a4 = L^-T w, then the n-vector bookkeeping for X gamma_new.
+__device__ __forceinline__ double bnr_readlane(double v, int srclane)
 {
-    __shared__ double sD[BNR_NB * BNR_NB], sB[BNR_NB * BNR_NB], sLp[BNR_NB * (BNR_NB + 1)], sLi[BNR_NB * (BNR_NB + 1)], sInv[BNR_NB * BNR_NB];
-    __shared__ int sfail;
-    const int ib = p + blockIdx.x, tid = threadIdx.x;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, srclane);
+    hi = __builtin_amdgcn_readlane(hi, srclane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bnr_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    e = fma(-x * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    return y;
+}
+
+#define BNR_LP (BNR_NB + 1)
+// number of workgroups of launch p
+__host__ __device__ inline int bnr_chol_npanel(int nbk, int p) { return (nbk - p) + 1 + (p + 1); }
+__host__ __device__ inline int bnr_chol_ntile(int nbk, int p)
+{
+    if (p == 0) return 0;
+    int m = nbk - (p + 1);
+    return m * (m + 1) / 2 + m + p * m;          // A tiles, b-row tiles, identity-row tiles (r <= p-1)
+}
+
+__global__ __launch_bounds__(256) void k_chol_step(bnr_dev cd, int p)
+{
+    __shared__ double sD[BNR_NB * BNR_LP], sB[BNR_NB * BNR_LP], sLp[BNR_NB * BNR_LP], sLi[BNR_NB * BNR_LP];
+    const int tid = threadIdx.x, nbk = cd.n_pad / BNR_NB;
     const size_t ld = cd.n_pad;
-    const int r = tid & 31, c0 = tid >> 5;           // thread owns elements (r, c0 + 8*m), m = 0..3
-    double accD[4], accB[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        int c = c0 + 8 * m;
-        accD[m] = cd.G[(size_t)(p * BNR_NB + r) + ld * (p * BNR_NB + c)];
-        accB[m] = cd.G[(size_t)(ib * BNR_NB + r) + ld * (p * BNR_NB + c)];
-    }
-    for (int kb = 0; kb < p; ++kb) {
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            int c = c0 + 8 * m;
-            sLp[r + (BNR_NB + 1) * c] = cd.G[(size_t)(p * BNR_NB + r) + ld * (kb * BNR_NB + c)];
-            sLi[r + (BNR_NB + 1) * c] = cd.G[(size_t)(ib * BNR_NB + r) + ld * (kb * BNR_NB + c)];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            int c = c0 + 8 * m;
-            double d = accD[m], b = accB[m];
-            for (int k = 0; k < BNR_NB; ++k) {
-                double lpc = sLp[c + (BNR_NB + 1) * k];
-                d = fma(-sLp[r + (BNR_NB + 1) * k], lpc, d);
-                b = fma(-sLi[r + (BNR_NB + 1) * k], lpc, b);
+    const int npanel = bnr_chol_npanel(nbk, p);
+    const int r = tid & 31, c0 = tid >> 5;                 // thread owns elements (r, c0 + 8 m), m = 0..3
+    const int pc = p * BNR_NB;
+    if ((int)blockIdx.x >= npanel) {
+        // ------------------------------------------------ role B: blk[.,j] -= blk[.,p-1] L[j,p-1]'
+        const int m = nbk - (p + 1);
+        int t = blockIdx.x - npanel;
+        const int ntri = m * (m + 1) / 2;
+        const int kc = pc - BNR_NB;
+        if (t >= ntri && t < ntri + m) {
+            const int j = p + 1 + (t - ntri);              // b row
+            if (tid < BNR_NB) {
+                double acc = cd.bw[j * BNR_NB + tid];
+                for (int k = 0; k < BNR_NB; ++k) acc = fma(-cd.bw[kc + k], cd.G[(size_t)(j * BNR_NB + tid) + ld * (kc + k)], acc);
+                cd.bw[j * BNR_NB + tid] = acc;
             }
-            accD[m] = d; accB[m] = b;
+            return;
         }
-    }
-    __syncthreads();
+        int i, j, ident;
+        if (t < ntri) {
+            int ti = 0;
+            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+            int tj = t - ti * (ti + 1) / 2;
+            i = p + 1 + ti; j = p + 1 + tj; ident = 0;
+        } else {
+            t -= ntri + m;
+            i = t / m; j = p + 1 + t % m; ident = 1;       // identity block row i (<= p-1)
+        }
 #pragma unroll
-    for (int m = 0; m < 4; ++m) { int c = c0 + 8 * m; sD[r + BNR_NB * c] = accD[m]; sB[r + BNR_NB * c] = accB[m]; }
-    if (tid == 0) sfail = 0;
-    __syncthreads();
-    // potrf of the 32 x 32 diagonal block (right-looking; rows = first 32 threads)
-    for (int j = 0; j < BNR_NB; ++j) {
-        double d = sD[j + BNR_NB * j];
-        if (!(d > 0.0) || !isfinite(d)) { if (tid == 0) sfail = 1; d = 1.0; }
-        d = sqrt(d);
-        __syncthreads();
-        if (tid == j) sD[j + BNR_NB * j] = d;
-        else if (tid > j && tid < BNR_NB) sD[tid + BNR_NB * j] = sD[tid + BNR_NB * j] / d;
-        __syncthreads();
-        int m = BNR_NB - j - 1;
-        for (int idx = tid; idx < m * m; idx += blockDim.x) {
-            int c = j + 1 + idx / m, i = j + 1 + idx % m;
-            if (i >= c) sD[i + BNR_NB * c] = fma(-sD[i + BNR_NB * j], sD[c + BNR_NB * j], sD[i + BNR_NB * c]);
+        for (int mm = 0; mm < 4; ++mm) {
+            int c = c0 + 8 * mm;
+            // Linv^T block (i, kc-block) is stored transposed in Winv: element (r,c) at Winv[(kc + c) + ld*(i*NB + r)]
+            sLi[r + BNR_LP * c] = ident ? cd.Winv[(size_t)(kc + c) + ld * (i * BNR_NB + r)] : cd.G[(size_t)(i * BNR_NB + r) + ld * (kc + c)];
+            sLp[r + BNR_LP * c] = cd.G[(size_t)(j * BNR_NB + r) + ld * (kc + c)];
         }
         __syncthreads();
-    }
-    // inverse of the lower-triangular block: column c by thread c (forward substitution)
-    if (tid < BNR_NB) {
-        int c = tid;
-        for (int i = 0; i < BNR_NB; ++i) {
-            double sacc = (i == c) ? 1.0 : 0.0;
-            for (int k = c; k < i; ++k) sacc = fma(-sD[i + BNR_NB * k], sInv[k + BNR_NB * c], sacc);
-            sInv[i + BNR_NB * c] = (i < c) ? 0.0 : sacc / sD[i + BNR_NB * i];
-        }
-    }
-    __syncthreads();
-    if (sfail && tid == 0 && blockIdx.x == 0) atomicAdd((unsigned long long *)&cd.counters[3], 1ull);
-    if (blockIdx.x == 0) {
+        if (!ident) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            int c = c0 + 8 * m;
-            cd.G[(size_t)(p * BNR_NB + r) + ld * (p * BNR_NB + c)] = (r >= c) ? sD[r + BNR_NB * c] : 0.0;
-            cd.invD[(size_t)p * BNR_NB * BNR_NB + r + BNR_NB * c] = sInv[r + BNR_NB * c];
+            for (int mm = 0; mm < 4; ++mm) {
+                int c = c0 + 8 * mm;
+                double *dst = cd.G + (size_t)(i * BNR_NB + r) + ld * (j * BNR_NB + c);
+                double acc = *dst;
+#pragma unroll 8
+                for (int k = 0; k < BNR_NB; ++k) acc = fma(-sLi[r + BNR_LP * k], sLp[c + BNR_LP * k], acc);
+                *dst = acc;
+            }
+        } else {
+            // transposed store: thread owns (row c0 + 8 mm of the block, column r) so that stores are contiguous in r
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                int rr2 = c0 + 8 * mm;                      // row of the (i,j) block
+                double *dst = cd.Winv + (size_t)(j * BNR_NB + r) + ld * (i * BNR_NB + rr2);   // element (rr2, r)
+                double acc = (p - 1 == i) ? 0.0 : *dst;     // first update of this identity row: the block starts at zero
+#pragma unroll 8
+                for (int k = 0; k < BNR_NB; ++k) acc = fma(-sLi[rr2 + BNR_LP * k], sLp[r + BNR_LP * k], acc);
+                *dst = acc;
+            }
         }
+        return;
+    }
+    // ---------------------------------------------------- role A: panel workgroup
+    const int b = blockIdx.x;
+    int kind, i;
+    if (b < nbk - p) { kind = 0; i = p + b; }              // block row i of G + I
+    else if (b == nbk - p) { kind = 1; i = 0; }            // b row
+    else { kind = 2; i = b - (nbk - p) - 1; }              // identity block row i (0..p)
+    const int kc = pc - BNR_NB;
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) {
+        int c = c0 + 8 * mm;
+        sD[r + BNR_LP * c] = cd.G[(size_t)(pc + r) + ld * (pc + c)];
+        double v;
+        if (kind == 0) v = cd.G[(size_t)(i * BNR_NB + r) + ld * (pc + c)];
+        else if (kind == 1) v = (r == 0) ? cd.bw[pc + c] : 0.0;
+        else v = (i == p) ? ((r == c) ? 1.0 : 0.0) : ((i == p - 1) ? 0.0 : cd.Winv[(size_t)(pc + c) + ld * (i * BNR_NB + r)]);
+        sB[r + BNR_LP * c] = v;
+        if (p > 0) {
+            sLp[r + BNR_LP * c] = cd.G[(size_t)(pc + r) + ld * (kc + c)];
+            double w;
+            if (kind == 0) w = cd.G[(size_t)(i * BNR_NB + r) + ld * (kc + c)];
+            else if (kind == 1) w = (r == 0) ? cd.bw[kc + c] : 0.0;
+            else w = (i <= p - 1) ? cd.Winv[(size_t)(kc + c) + ld * (i * BNR_NB + r)] : 0.0;
+            sLi[r + BNR_LP * c] = w;
+        }
+    }
+    __syncthreads();
+    if (p > 0) {
+        double accD[4], accB[4];
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            int c = c0 + 8 * mm;
+            double d = sD[r + BNR_LP * c], bb = sB[r + BNR_LP * c];
+#pragma unroll 8
+            for (int k = 0; k < BNR_NB; ++k) {
+                double lpc = sLp[c + BNR_LP * k];
+                d = fma(-sLp[r + BNR_LP * k], lpc, d);
+                bb = fma(-sLi[r + BNR_LP * k], lpc, bb);
+            }
+            accD[mm] = d; accB[mm] = bb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) { int c = c0 + 8 * mm; sD[r + BNR_LP * c] = accD[mm]; sB[r + BNR_LP * c] = accB[mm]; }
+        __syncthreads();
+    }
+    if (tid < 64) {
+        // panel sweep, lane = row: lanes 0..31 rows of the diagonal block, lanes 32..63 rows of the own block
+        const int lane = tid, rr = lane & 31;
+        const double *src = (lane < 32) ? sD : sB;
+        double a[BNR_NB];
+#pragma unroll
+        for (int c = 0; c < BNR_NB; ++c) a[c] = src[rr + BNR_LP * c];
+        int bad = 0;
+#pragma unroll
+        for (int j = 0; j < BNR_NB; ++j) {
+            double piv = bnr_readlane(a[j], j);
+            if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
+            double rinv = bnr_rsqrt(piv);
+            double lj = a[j] * rinv;
+            a[j] = lj;
+#pragma unroll
+            for (int k = j + 1; k < BNR_NB; ++k) {
+                double lk = bnr_readlane(lj, k);
+                a[k] = fma(-lj, lk, a[k]);
+            }
+        }
+        if (bad && lane == 0 && b == 0) atomicAdd((unsigned long long *)&cd.counters[3], 1ull);
+        double *dstl = (lane < 32) ? sD : sB;
+#pragma unroll
+        for (int c = 0; c < BNR_NB; ++c) dstl[rr + BNR_LP * c] = (lane < 32 && c > rr) ? 0.0 : a[c];
+    }
+    __syncthreads();
+    if (kind == 0) {
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            int c = c0 + 8 * mm;
+            if (b == 0) cd.G[(size_t)(pc + r) + ld * (pc + c)] = sD[r + BNR_LP * c];
+            else cd.G[(size_t)(i * BNR_NB + r) + ld * (pc + c)] = sB[r + BNR_LP * c];
+        }
+    } else if (kind == 1) {
+        if (tid < BNR_NB) cd.bw[pc + tid] = sB[BNR_LP * tid];
     } else {
-        // L[i,p] = B * inv(L[p,p])'  : out[r][c] = sum_{k<=c} B[r][k] * Inv[c][k]
+        // (L^-T)[i-block row rr2, p-block col r] -> Winv[(pc + r) + ld*(i*NB + rr2)]  (contiguous in r)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            int c = c0 + 8 * m;
-            double sacc = 0.0;
-            for (int k = 0; k <= c; ++k) sacc = fma(sB[r + BNR_NB * k], sInv[c + BNR_NB * k], sacc);
-            cd.G[(size_t)(ib * BNR_NB + r) + ld * (p * BNR_NB + c)] = sacc;
+        for (int mm = 0; mm < 4; ++mm) {
+            int rr2 = c0 + 8 * mm;
+            cd.Winv[(size_t)(pc + r) + ld * (i * BNR_NB + rr2)] = sB[rr2 + BNR_LP * r];
         }
     }
 }
 
-// ===================================================================================== k_solve
-// One block of 1024 threads.  Finishes the GEMVs, forms the right-hand side, solves (G+I) a4 = a1 - a3 with the
-// blocked factor, and produces X gamma_new from n-vectors:
-//   a1 = (y - X W - mu_prev)/tau, a3 = X sz + z2   (gibbs.jl:432-433; note (X/tau) Delta_gamma1 = X sz)
-//   X gamma_new = X W + tau X sz + tau G a4,  G a4 = (a1 - a3) - a4.
-__global__ __launch_bounds__(1024) void k_solve(bnr_dev cd, int s)
+// Right-hand side: finishes the GEMVs of k_xpass and forms b = a1 - a3 (gibbs.jl:432-434):
+//   a1 = (y - X W - mu_prev)/tau, a3 = X sz + z2  (note (X/tau) Delta_gamma1 = X sz).
+// grid = n_pad/64 blocks of 256 threads: 64 rows x 4 partial groups; fixed summation order (deterministic).
+__global__ __launch_bounds__(256) void k_rhs(bnr_dev cd, int s)
 {
-    extern __shared__ double sh[];          // n_pad (rhs / solution) + 32 (block solution)
-    double *sb = sh, *sx = sh + cd.n_pad;
-    const bnr_plan_entry P = cd.plan[s];
+    __shared__ double sw[4][64], sa[4][64];
+    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     const double *prev = cd.trace + (size_t)P.prev * cd.rowlen;
     const double tau = cd.scal[SC_TAU], mu = prev[ROW_MU];
-    const int n = cd.n, np = cd.n_pad, tid = threadIdx.x, nb = np / BNR_NB;
-    const size_t ld = np;
-    for (int i = tid; i < np; i += blockDim.x) {
-        double xw = 0.0, xs = 0.0;
-        for (int b = 0; b < cd.nblk_x; ++b) { xw += cd.PW[(size_t)b * ld + i]; xs += cd.PA[(size_t)b * ld + i]; }
-        double z2 = (i < n) ? bnr_normal(cd.seed, P.it, SITE_G_Z2, (uint32_t)i, 0) : 0.0;
-        double a3 = xs + z2;
-        double bb = (i < n) ? ((cd.y[i] - xw - mu) / tau - a3) : 0.0;
-        cd.xw[i] = xw; cd.a3[i] = xs;          // a3 buffer keeps X sz (without z2)
-        sb[i] = bb;
+    const int n = cd.n;
+    const size_t ld = cd.n_pad;
+    const int il = threadIdx.x & 63, g = threadIdx.x >> 6, i = blockIdx.x * 64 + il;
+    double xw = 0.0, xs = 0.0;
+    const int nb = cd.nblk_x;
+    int b = g;
+    for (; b + 28 < nb; b += 32) {
+        double w[8], a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { w[u] = cd.PW[(size_t)(b + 4 * u) * ld + i]; a[u] = cd.PA[(size_t)(b + 4 * u) * ld + i]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { xw += w[u]; xs += a[u]; }
     }
+    for (; b < nb; b += 4) { xw += cd.PW[(size_t)b * ld + i]; xs += cd.PA[(size_t)b * ld + i]; }
+    sw[g][il] = xw; sa[g][il] = xs;
     __syncthreads();
-    // keep rhs for later
-    for (int i = tid; i < np; i += blockDim.x) cd.res[i] = sb[i];     // res used as scratch for b here
-    // forward: L w = b
-    for (int p = 0; p < nb; ++p) {
-        if (tid < BNR_NB) {
-            const double *inv = cd.invD + (size_t)p * BNR_NB * BNR_NB;
-            double acc = 0.0;
-            for (int k = 0; k <= tid; ++k) acc = fma(inv[tid + BNR_NB * k], sb[p * BNR_NB + k], acc);
-            sx[tid] = acc;
-        }
-        __syncthreads();
-        if (tid < BNR_NB) sb[p * BNR_NB + tid] = sx[tid];
-        for (int i = (p + 1) * BNR_NB + tid; i < np; i += blockDim.x) {
-            double acc = sb[i];
-            const double *Lp = cd.G + (size_t)i + ld * (size_t)(p * BNR_NB);
-#pragma unroll 8
-            for (int k = 0; k < BNR_NB; ++k) acc = fma(-Lp[(size_t)k * ld], sx[k], acc);
-            sb[i] = acc;
-        }
-        __syncthreads();
+    if (g == 0) {
+        xw = (sw[0][il] + sw[1][il]) + (sw[2][il] + sw[3][il]);
+        xs = (sa[0][il] + sa[1][il]) + (sa[2][il] + sa[3][il]);
+        double z2 = (i < n) ? bnr_normal(cd.seed, P.it, SITE_G_Z2, (uint32_t)i, 0) : 0.0;
+        double bb = (i < n) ? ((cd.y[i] - xw - mu) / tau - (xs + z2)) : 0.0;
+        cd.xw[i] = xw; cd.a3[i] = xs;          // a3 buffer keeps X sz (without z2)
+        cd.bw[i] = bb; cd.res[i] = bb;         // bw is overwritten by w = L^-1 b; res keeps b
     }
-    // backward: L' a4 = w
-    for (int p = nb - 1; p >= 0; --p) {
-        if (tid < BNR_NB) {
-            const double *inv = cd.invD + (size_t)p * BNR_NB * BNR_NB;
-            double acc = 0.0;
-            for (int k = tid; k < BNR_NB; ++k) acc = fma(inv[k + BNR_NB * tid], sb[p * BNR_NB + k], acc);   // inv' row
-            sx[tid] = acc;
-        }
-        __syncthreads();
-        if (tid < BNR_NB) sb[p * BNR_NB + tid] = sx[tid];
-        for (int i = tid; i < p * BNR_NB; i += blockDim.x) {
-            double acc = sb[i];
-            const double *Lp = cd.G + (size_t)(p * BNR_NB) + ld * (size_t)i;     // L[p*NB + k, i]
-#pragma unroll 8
-            for (int k = 0; k < BNR_NB; ++k) acc = fma(-Lp[k], sx[k], acc);
-            sb[i] = acc;
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < np; i += blockDim.x) {
-        double a4 = sb[i], b = cd.res[i];
-        cd.a4[i] = a4;
-        cd.xg[i] = (i < n) ? (cd.xw[i] + tau * cd.a3[i] + tau * (b - a4)) : 0.0;
+}
+
+// a4 = L^-T w : a4_r = sum_{c >= r} Linv[c, r] w_c = <column r of Winv, w>   (one wavefront per row r), then
+//   X gamma_new = X W + tau X sz + tau G a4,  G a4 = b - a4   (no third pass over X).  grid = n_pad/4 blocks of 256.
+__global__ __launch_bounds__(256) void k_solve_gemv(bnr_dev cd)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rrow = blockIdx.x * 4 + wave;
+    const size_t ld = cd.n_pad;
+    const double *col = cd.Winv + ld * (size_t)rrow;
+    const int cstart = (rrow / BNR_NB) * BNR_NB;       // Winv is lower triangular: entries c >= r (block granularity)
+    double acc = 0.0;
+    for (int cc = cstart + lane; cc < cd.n_pad; cc += 64) acc = fma(col[cc], cd.bw[cc], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        const double tau = cd.scal[SC_TAU];
+        double b = cd.res[rrow];
+        cd.a4[rrow] = acc;
+        cd.xg[rrow] = (rrow < cd.n) ? (cd.xw[rrow] + tau * cd.a3[rrow] + tau * (b - acc)) : 0.0;
     }
 }
 
@@ -544,7 +648,7 @@ __global__ __launch_bounds__(256) void k_backproj(bnr_dev cd, int s, int flags)
 {
     extern __shared__ double sh[];          // n_pad (a4) + 64 (dots)
     double *sa = sh, *sdot = sh + cd.n_pad;
-    const bnr_plan_entry P = cd.plan[s];
+    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     double *row = cd.trace + (size_t)P.row * cd.rowlen;
     const double *prev = cd.trace + (size_t)P.prev * cd.rowlen;
     const int R = cd.R, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -614,7 +718,7 @@ __global__ __launch_bounds__(1024) void k_tail(bnr_dev cd, int s, int mask, int 
     __shared__ double sPsi[BNR_RMAX * BNR_RMAX], sA[BNR_RMAX * BNR_RMAX], sT[BNR_RMAX * BNR_RMAX], sBm[BNR_RMAX * BNR_RMAX];
     __shared__ double sll[3 * BNR_RMAX], slam[BNR_RMAX];
     __shared__ double sval[8];
-    const bnr_plan_entry P = cd.plan[s];
+    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     double *row = cd.trace + (size_t)P.row * cd.rowlen;
     const double *prev = cd.trace + (size_t)P.prev * cd.rowlen;
     const int R = cd.R, V = cd.V, q = cd.q, n = cd.n, tid = threadIdx.x;
@@ -794,6 +898,9 @@ __global__ __launch_bounds__(1024) void k_tail(bnr_dev cd, int s, int mask, int 
     }
     if (cap && tid == 0) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
 }
+
+// advances the plan base after a batch of sweeps (last node of the captured graph)
+__global__ void k_advance(int *pbase, int by) { if (threadIdx.x == 0 && blockIdx.x == 0) pbase[0] += by; }
 
 // ===================================================================================== k_init_prior
 // initialize_variables! (gibbs.jl:191-224) into row 0.  One block of 256 threads.
