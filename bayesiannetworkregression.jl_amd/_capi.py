@@ -52,6 +52,8 @@ _SIGS = {
     "bnr_chain_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "bnr_chain_last_timing": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "bnr_chain_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "bnr_chain_debug_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32]),
+    "bnr_chain_debug_copy": (C.c_int, [C.c_void_p, C.c_int32, _dp, C.c_int64]),
     "bnr_host_philox": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "bnr_host_uniform2": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
     "bnr_host_normal": (C.c_double, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -214,7 +216,7 @@ class Chain:
     def counters(self):
         out = (C.c_int64 * 8)()
         check(self.L.bnr_chain_counters(self.h, out))
-        return dict(jitter=out[0], nan_w=out[1], sampler_cap=out[2], chol_fail=out[3])
+        return dict(jitter=out[0], nan_w=out[1], sampler_cap=out[2], chol_fail=out[3], where=list(out[4:8]))
 
     def set_profiling(self, on=True):
         check(self.L.bnr_chain_set_profiling(self.h, 1 if on else 0))
@@ -223,6 +225,16 @@ class Chain:
         us, n = C.c_double(0), C.c_int64(0)
         check(self.L.bnr_chain_last_timing(self.h, which, C.byref(us), C.byref(n)))
         return us.value, n.value
+
+    def debug_read(self, count=1024):
+        out = (C.c_uint64 * count)()
+        check(self.L.bnr_chain_debug_read(self.h, out, count))
+        return np.array(out[:], dtype=np.uint64)
+
+    def debug_copy(self, which, count):
+        out = np.empty(count)
+        check(self.L.bnr_chain_debug_copy(self.h, which, _ptr(out), count))
+        return out
 
     def set_option(self, name, value):
         check(self.L.bnr_chain_set_option(self.h, name.encode(), int(value)))

@@ -23,7 +23,10 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 struct bnr_chain {
     bnr_dev d{};
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: the Gram branch of a sweep
+    std::vector<hipEvent_t> fj;                         // fork/join events
+    size_t fj_next = 0;
+    int overlap = 1;
     std::vector<void *> allocs;
     bnr_plan_entry *plan_dev = nullptr, *plan_pin = nullptr;
     int plan_cap = 0;
@@ -40,7 +43,7 @@ struct bnr_chain {
     // profiling
     int profiling = 0;
     std::vector<hipEvent_t> ev;  // pairs around k_gram, plus [begin,end] of the run
-    double t_gram_us = 0, t_iter_us = 0;
+    double t_gram_us = 0, t_iter_us = 0, t_gram_acc = 0;
     int64_t n_gram = 0, n_iter = 0;
     size_t trace_bytes = 0;
 };
@@ -149,6 +152,7 @@ int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const dou
     int *ek = nullptr, *el = nullptr;
 #define TRY(x) do { rc = (x); if (rc) { bnr_chain_destroy(c); return rc; } } while (0)
     TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess ? BNR_OK : fail(BNR_ERR_HIP, "hipStreamCreate failed"));
+    TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess ? BNR_OK : fail(BNR_ERR_HIP, "hipStreamCreate failed"));
     TRY(dev_alloc(c, &Xd, (size_t)d.n_pad * d.q_pad));
     TRY(dev_alloc(c, &yd, d.n_pad));
     TRY(dev_alloc(c, &ek, d.q));
@@ -171,8 +175,7 @@ int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const dou
     TRY(dev_alloc(c, &d.PA, (size_t)d.nblk_x * d.n_pad));
     TRY(dev_alloc(c, &d.PG, (size_t)d.nblk_x * d.n_pad));
     TRY(dev_alloc(c, &d.Gpart, (size_t)d.ksplit * ntl * BNR_GT * BNR_GT));
-    TRY(dev_alloc(c, &d.G, (size_t)d.n_pad * d.n_pad));
-    TRY(dev_alloc(c, &d.Winv, (size_t)d.n_pad * d.n_pad));
+    TRY(dev_alloc(c, &d.E, (size_t)bnr_ldE(d.n_pad) * d.n_pad));
     TRY(dev_alloc(c, &d.a3, d.n_pad));
     TRY(dev_alloc(c, &d.xw, d.n_pad));
     TRY(dev_alloc(c, &d.a4, d.n_pad));
@@ -180,14 +183,17 @@ int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const dou
     TRY(dev_alloc(c, &d.xg, d.n_pad));
     TRY(dev_alloc(c, &d.bw, d.n_pad));
     TRY(dev_alloc(c, &d.scal, 16));
+    TRY(dev_alloc(c, &d.Minv, BNR_RMAX * BNR_RMAX + 1));
     TRY(dev_alloc(c, &d.Psum, (size_t)d.nblk_bp * (1 + 3 * R)));
-    TRY(dev_alloc(c, &d.counters, 8));
+    TRY(dev_alloc(c, &d.counters, 16));
+    TRY(dev_alloc(c, &d.stamp, 4 * ntl));
+    TRY(dev_alloc(c, &d.dbg, 1024));
     c->plan_cap = 1 << 16;
     TRY(dev_alloc(c, &c->plan_dev, c->plan_cap));
     TRY(dev_alloc(c, &c->pbase_dev, 4));
     d.pbase = c->pbase_dev;
     if (hipHostMalloc((void **)&c->plan_pin, sizeof(bnr_plan_entry) * c->plan_cap) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipHostMalloc failed"); }
-    if (hipHostMalloc((void **)&c->counters_host, sizeof(long long) * 8) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipHostMalloc failed"); }
+    if (hipHostMalloc((void **)&c->counters_host, sizeof(long long) * 16) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipHostMalloc failed"); }
     d.plan = c->plan_dev;
 #undef TRY
     *out = c;
@@ -205,6 +211,8 @@ int bnr_chain_destroy(bnr_chain *c)
     if (!c) return BNR_OK;
     hipSetDevice(c->device);
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+    if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
+    for (hipEvent_t e : c->fj) hipEventDestroy(e);
     drop_graph(c);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     for (void *p : c->allocs) hipFree(p);
@@ -246,56 +254,98 @@ static int check_launch(const char *what)
     return BNR_OK;
 }
 
-static void launch_node(bnr_chain *c, int s, int mode) { hipLaunchKernelGGL(k_node, dim3(c->d.V), dim3(64), 0, c->stream, c->d, s, mode); }
+static void launch_node(bnr_chain *c, int s, int mode)
+{ hipLaunchKernelGGL(k_node, dim3(c->d.V), dim3(64), 64 * (2 * c->d.R + 1) * sizeof(double), c->stream, c->d, s, mode); }
 static void launch_xpass(bnr_chain *c, int s, int which)
 { hipLaunchKernelGGL(k_xpass, dim3(c->d.nblk_x), dim3(256), 3 * c->d.chunk_x * sizeof(double), c->stream, c->d, s, which); }
-static void launch_factor(bnr_chain *c, int s, bool timed)
+static void launch_gram(bnr_chain *c, int s, hipStream_t st, bool timed)
 {
     const bnr_dev &d = c->d;
     const int ntl = d.ntile * (d.ntile + 1) / 2;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
-        hipEventCreate(&e0); hipEventCreate(&e1);
-        c->ev.push_back(e0); c->ev.push_back(e1);
-        hipEventRecord(e0, c->stream);
+        while (c->ev.size() < (size_t)(2 * (s + 1))) { hipEvent_t e; hipEventCreate(&e); c->ev.push_back(e); }
+        e0 = c->ev[2 * s]; e1 = c->ev[2 * s + 1];
+        hipEventRecord(e0, st);
     }
-    hipLaunchKernelGGL(k_gram, dim3(ntl, d.ksplit), dim3(1024), 0, c->stream, c->d, s);
-    if (timed) hipEventRecord(e1, c->stream);
-    hipLaunchKernelGGL(k_gram_reduce, dim3(ntl, 4), dim3(256), 0, c->stream, c->d);
-    hipLaunchKernelGGL(k_rhs, dim3(d.n_pad / 64), dim3(256), 0, c->stream, c->d, s);
-    const int nbk = d.n_pad / BNR_NB;
-    for (int p = 0; p < nbk; ++p)
-        hipLaunchKernelGGL(k_chol_step, dim3(bnr_chol_npanel(nbk, p) + bnr_chol_ntile(nbk, p)), dim3(256), 0, c->stream, c->d, p);
+    hipLaunchKernelGGL(k_gram, dim3(ntl, d.ksplit), dim3(1024), 0, st, c->d, s);
+    if (timed) hipEventRecord(e1, st);
+    hipLaunchKernelGGL(k_gram_reduce, dim3(ntl, 4), dim3(256), 0, st, c->d, s);
 }
-static void launch_solve(bnr_chain *c, int s)
-{ (void)s; hipLaunchKernelGGL(k_solve_gemv, dim3(c->d.n_pad / 4), dim3(256), 0, c->stream, c->d); }
+static void launch_rhs(bnr_chain *c, int s) { hipLaunchKernelGGL(k_rhs, dim3(c->d.n_pad / 64), dim3(256), 0, c->stream, c->d, s); }
+static void launch_chol(bnr_chain *c, int s)
+{
+    const int nbk = c->d.n_pad / BNR_NB;
+    hipLaunchKernelGGL(k_rhs_place, dim3((c->d.n_pad + 255) / 256), dim3(256), 0, c->stream, c->d);
+    for (int p = 0; p < nbk; ++p)
+        hipLaunchKernelGGL(k_chol_step, dim3(bnr_chol_npanel(nbk, p) + bnr_chol_ntile(nbk, p)), dim3(256), 0, c->stream, c->d, p, s);
+}
+static void launch_solve(bnr_chain *c)
+{ hipLaunchKernelGGL(k_solve_gemv, dim3(c->d.n_pad / BNR_NB), dim3(256), (c->d.n_pad + 256) * sizeof(double), c->stream, c->d); }
 static void launch_backproj(bnr_chain *c, int s, int flags)
 { hipLaunchKernelGGL(k_backproj, dim3(c->d.nblk_bp), dim3(256), (c->d.n_pad + 64) * sizeof(double), c->stream, c->d, s, flags); }
 static void launch_tail(bnr_chain *c, int s, int mask, int xg_src)
 { hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), 0, c->stream, c->d, s, mask, xg_src); }
-
-// one full sweep for plan slot s (gibbs_sample!, gibbs.jl:663-677)
-static void launch_sweep(bnr_chain *c, int s)
+static hipEvent_t next_event(bnr_chain *c)
 {
+    if (c->fj_next >= c->fj.size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); c->fj.push_back(e); }
+    return c->fj[c->fj_next++];
+}
+
+// One sweep for plan slot s (gibbs_sample!, gibbs.jl:663-677).  The scalar tail of the PREVIOUS sweep (theta, Delta, M,
+// mu, Lambda, pi and the carried sums) is issued at the head of this one, because together with update_tau2!/update_u_xi!
+// and the X W pass it is independent of the Gram matrix X diag(S) X' of this sweep: the two branches run concurrently
+// (fork/join on two streams, also inside the captured graph) and meet before the factorization.
+//   branch A (stream):  tail(s-1) -> k_node(s) -> k_xpass(s) -> k_rhs(s)
+//   branch B (stream2): k_gram(s) -> k_gram_reduce
+//   joined:             k_chol_step x nbk -> k_solve_gemv -> k_backproj(s)
+static void launch_sweep(bnr_chain *c, int s, bool prev_tail)
+{
+    const bool timed = c->profiling != 0;
+    const bool overlap = c->overlap != 0;
+    if (overlap) {
+        hipEvent_t ef = next_event(c), ej = next_event(c);
+        hipEventRecord(ef, c->stream);
+        hipStreamWaitEvent(c->stream2, ef, 0);
+        launch_gram(c, s, c->stream2, timed);
+        hipEventRecord(ej, c->stream2);
+    }
+    if (prev_tail) launch_tail(c, s - 1, 1023, 0);
     launch_node(c, s, 3);
     launch_xpass(c, s, 3);
-    launch_factor(c, s, c->profiling != 0);
-    launch_solve(c, s);
+    launch_rhs(c, s);
+    if (overlap) hipStreamWaitEvent(c->stream, c->fj[c->fj_next - 1], 0);
+    else launch_gram(c, s, c->stream, timed);
+    launch_chol(c, s);
+    launch_solve(c);
     launch_backproj(c, s, 7);
-    launch_tail(c, s, 255, 0);
 }
 
 // Enqueue `count` consecutive sweeps starting at the current plan base.  Full batches of graph_k sweeps replay one
 // captured hipGraph (kernel boundaries without host launch cost); the remainder is launched eagerly.
+// with profiling on: after a batch, read the HIP events recorded around the k_gram launches of that batch (recorded on
+// the stream the kernel runs on)
+static int collect_gram_times(bnr_chain *c, int nsweeps)
+{
+    if (!c->profiling) return BNR_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int s = 0; s < nsweeps; ++s) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev[2 * s], c->ev[2 * s + 1]) == hipSuccess) { c->t_gram_acc += ms; c->n_gram += 1; }
+    }
+    return BNR_OK;
+}
+
 static int launch_range(bnr_chain *c, int count)
 {
     int done = 0;
-    if (c->use_graph && !c->profiling && c->graph_k > 0) {
+    if (c->use_graph && !c->profiling && c->graph_k > 0) {     // profiling records HIP events around k_gram: eager launches
         const int K = c->graph_k;
         while (count - done >= K) {
             if (!c->gexec) {
+                c->fj_next = 0;
                 HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-                for (int s = 0; s < K; ++s) launch_sweep(c, s);
+                for (int s = 0; s < K; ++s) launch_sweep(c, s, true);
                 hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, c->stream, c->pbase_dev, K);
                 HIPCHK(hipStreamEndCapture(c->stream, &c->graph));
                 HIPCHK(hipGraphInstantiate(&c->gexec, c->graph, nullptr, nullptr, 0));
@@ -305,8 +355,13 @@ static int launch_range(bnr_chain *c, int count)
         }
     }
     const int r = count - done;
-    for (int s = 0; s < r; ++s) launch_sweep(c, s);
-    if (r > 0) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, c->stream, c->pbase_dev, r);
+    c->fj_next = 0;
+    for (int s = 0; s < r; ++s) launch_sweep(c, s, true);
+    if (r > 0) {
+        hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, c->stream, c->pbase_dev, r);
+        int rc = collect_gram_times(c, r);
+        if (rc) return rc;
+    }
     return BNR_OK;
 }
 
@@ -321,7 +376,7 @@ static int refresh_carried(bnr_chain *c, int r)
     rc = upload_plan(c, 1);
     if (rc) return rc;
     launch_xpass(c, 0, 4);
-    launch_tail(c, 0, 64, 1);
+    launch_tail(c, 0, 64 | 256, 1);
     HIPCHK(hipStreamSynchronize(c->stream));
     c->carried_row = r;
     return check_launch("refresh");
@@ -329,9 +384,15 @@ static int refresh_carried(bnr_chain *c, int r)
 
 static int fetch_status(bnr_chain *c)
 {
-    HIPCHK(hipMemcpyAsync(c->counters_host, c->d.counters, sizeof(long long) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->counters_host, c->d.counters, sizeof(long long) * 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->counters_host[3] > 0) return fail(BNR_ERR_CHOLESKY, "Cholesky failed after the jitter ladder");
+    if (c->counters_host[8] > 0) return fail(BNR_ERR_HIP, "stream ordering violated: the factorization started before the Gram branch finished");
+    if (c->counters_host[3] > 0) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "Cholesky failed after the jitter ladder (node %lld, Psi %lld, M %lld, G+I %lld)", c->counters_host[4],
+                 c->counters_host[5], c->counters_host[6], c->counters_host[7]);
+        return fail(BNR_ERR_CHOLESKY, buf);
+    }
     return BNR_OK;
 }
 
@@ -358,9 +419,10 @@ static int enqueue_run(bnr_chain *c, int first_index, int nburn, int total, int 
     if (count <= 0) { c->next_row = first_index; return BNR_OK; }
     int rc = refresh_carried(c, first_index - 2);
     if (rc) return rc;
-    rc = ensure_plan(c, count);
+    rc = ensure_plan(c, count + 1);
     if (rc) return rc;
-    int j = first_index, prev = first_index - 2, s = 0, maxrow = 0;
+    c->plan_pin[0] = bnr_plan_entry{0u, 0, 0, 2};      // placeholder: the tail issued at the head of the first sweep is a no-op
+    int j = first_index, prev = first_index - 2, s = 1, maxrow = 0;
     for (int i = first_index; i <= total; ++i, ++s) {
         c->iter += 1;
         bnr_plan_entry e{(uint32_t)c->iter, j - 1, prev, 0};
@@ -371,8 +433,9 @@ static int enqueue_run(bnr_chain *c, int first_index, int nburn, int total, int 
         c->plan_pin[s] = e;
     }
     if (maxrow > c->d.tot) { c->iter -= count; return fail(BNR_ERR_BAD_ARG, "run would write past the table (tot_save too small)"); }
-    rc = upload_plan(c, count);
+    rc = upload_plan(c, count + 1);
     if (rc) return rc;
+    hipLaunchKernelGGL(k_setbase, dim3(1), dim3(1), 0, c->stream, c->pbase_dev, 1);
     c->next_row = j;
     c->carried_row = -1;
     return BNR_OK;
@@ -386,8 +449,7 @@ int bnr_chain_run(bnr_chain *c, int32_t first_index, int32_t nburn, int32_t tota
     int rc = enqueue_run(c, first_index, nburn, total, purge_burn);
     if (rc) return rc;
     const int count = total - first_index + 1;
-    for (hipEvent_t e : c->ev) hipEventDestroy(e);
-    c->ev.clear();
+    c->t_gram_acc = 0; c->n_gram = 0;
     hipEvent_t r0 = nullptr, r1 = nullptr;
     if (c->profiling) { hipEventCreate(&r0); hipEventCreate(&r1); hipEventRecord(r0, c->stream); }
     if (cb && prog_freq > 0) {
@@ -408,6 +470,7 @@ int bnr_chain_run(bnr_chain *c, int32_t first_index, int32_t nburn, int32_t tota
         rc = launch_range(c, count);
         if (rc) return rc;
     }
+    if (count > 0) launch_tail(c, -1, 1023, 0);                        // scalar tail of the last sweep
     if (c->profiling) hipEventRecord(r1, c->stream);
     rc = check_launch("sweep");
     if (rc) return rc;
@@ -416,13 +479,10 @@ int bnr_chain_run(bnr_chain *c, int32_t first_index, int32_t nburn, int32_t tota
         float ms = 0;
         hipEventElapsedTime(&ms, r0, r1);
         c->t_iter_us = 1e3 * ms / count; c->n_iter = count;
-        double acc = 0;
-        for (size_t k = 0; k + 1 < c->ev.size(); k += 2) { float m2 = 0; hipEventElapsedTime(&m2, c->ev[k], c->ev[k + 1]); acc += m2; }
-        c->n_gram = (int64_t)(c->ev.size() / 2);
-        c->t_gram_us = c->n_gram ? 1e3 * acc / c->n_gram : 0;
+        c->t_gram_us = c->n_gram ? 1e3 * c->t_gram_acc / c->n_gram : 0;
         hipEventDestroy(r0); hipEventDestroy(r1);
     }
-    if (count > 0) c->carried_row = c->plan_pin[count - 1].row;
+    if (count > 0) c->carried_row = c->plan_pin[count].row;
     if (next_row) *next_row = c->next_row;
     return fetch_status(c);
 }
@@ -437,10 +497,11 @@ int bnr_chain_run_async(bnr_chain *c, int32_t first_index, int32_t nburn, int32_
     int saved = c->profiling;
     c->profiling = 0;
     rc = launch_range(c, count);
+    if (!rc && count > 0) launch_tail(c, -1, 1023, 0);
     c->profiling = saved;
     if (rc) return rc;
     c->pending = true;
-    if (count > 0) c->carried_row = -2 - c->plan_pin[count - 1].row;    // becomes valid at sync
+    if (count > 0) c->carried_row = -2 - c->plan_pin[count].row;        // becomes valid at sync
     return check_launch("sweep");
 }
 
@@ -481,7 +542,8 @@ int bnr_gibbs_step(bnr_chain *c, int32_t row, int64_t iter)
 {
     int rc = hook_begin(c, row, iter, true);
     if (rc) return rc;
-    launch_sweep(c, 0);
+    launch_sweep(c, 0, false);
+    launch_tail(c, 0, 1023, 0);
     rc = hook_end(c, "gibbs_step");
     if (!rc) { c->carried_row = row - 1; c->iter = iter; }
     return rc;
@@ -497,7 +559,7 @@ int bnr_update_u_xi(bnr_chain *c, int32_t row, int64_t iter)
 {
     int rc = hook_begin(c, row, iter, false);
     if (rc) return rc;
-    launch_node(c, 0, 2);
+    launch_node(c, 0, 2 | 4);
     return hook_end(c, "update_u_xi");
 }
 int bnr_update_gamma(bnr_chain *c, int32_t row, int64_t iter)
@@ -506,8 +568,10 @@ int bnr_update_gamma(bnr_chain *c, int32_t row, int64_t iter)
     if (rc) return rc;
     launch_node(c, 0, 0);            // publishes tau = sqrt(tau2[row])
     launch_xpass(c, 0, 3);
-    launch_factor(c, 0, false);
-    launch_solve(c, 0);
+    launch_gram(c, 0, c->stream, false);
+    launch_rhs(c, 0);
+    launch_chol(c, 0);
+    launch_solve(c);
     launch_backproj(c, 0, 1);
     return hook_end(c, "update_gamma");
 }
@@ -739,14 +803,33 @@ int bnr_chain_counters(bnr_chain *c, int64_t out[8])
 {
     if (!c || !out) return fail(BNR_ERR_BAD_ARG, "NULL argument");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpy(c->counters_host, c->d.counters, sizeof(long long) * 8, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 8; ++i) out[i] = c->counters_host[i];
+    HIPCHK(hipMemcpy(c->counters_host, c->d.counters, sizeof(long long) * 16, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) out[i] = c->counters_host[i];   // [4..7]: where a hard Cholesky failure happened (node, Psi, M, G+I)
+    return BNR_OK;
+}
+
+int bnr_chain_debug_read(bnr_chain *c, uint64_t *out, int32_t count)
+{
+    if (!c || !out || count < 0 || count > 1024) return fail(BNR_ERR_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(out, c->d.dbg, sizeof(uint64_t) * count, hipMemcpyDeviceToHost));
+    return BNR_OK;
+}
+
+int bnr_chain_debug_copy(bnr_chain *c, int32_t which, double *out, int64_t count)
+{
+    if (!c || !out) return fail(BNR_ERR_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const double *src = which == 0 ? c->d.E : (which == 1 ? c->d.bw : (which == 2 ? c->d.a4 : c->d.Gpart));
+    HIPCHK(hipMemcpy(out, src, sizeof(double) * count, hipMemcpyDeviceToHost));
     return BNR_OK;
 }
 
 int bnr_chain_set_profiling(bnr_chain *c, int32_t enable)
 {
     if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
+    if (c->profiling != enable) drop_graph(c);       // the event-record nodes are part of the captured graph
     c->profiling = enable;
     return BNR_OK;
 }
@@ -763,6 +846,7 @@ int bnr_chain_set_option(bnr_chain *c, const char *name, int64_t value)
 {
     if (!c || !name) return fail(BNR_ERR_BAD_ARG, "NULL argument");
     if (!strcmp(name, "graph")) { c->use_graph = (int)value; return BNR_OK; }
+    if (!strcmp(name, "overlap")) { c->overlap = (int)value; drop_graph(c); return BNR_OK; }
     if (!strcmp(name, "graph_k")) { if (value < 1 || value > 256) return fail(BNR_ERR_BAD_ARG, "graph_k out of range"); c->graph_k = (int)value; drop_graph(c); return BNR_OK; }
     return fail(BNR_ERR_BAD_ARG, std::string("unknown option ") + name);
 }

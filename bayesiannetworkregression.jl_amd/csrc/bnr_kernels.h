@@ -45,24 +45,56 @@ struct bnr_dev {
     double *PW, *PA;             // nblk_x x n_pad GEMV partials (X W, X sz)
     double *PG;                  // nblk_x x n_pad GEMV partials (X gamma, refresh path)
     int nblk_x, chunk_x;
-    double *Gpart, *G, *Winv;    // Gram partial tiles, G (n_pad x n_pad col-major; holds L after the factorization), Winv = L^-1
+    double *Gpart, *E;           // Gram partial tiles; E = extended matrix of the factorization (see k_gram_reduce)
     int ksplit, ntile;           // ntile = n_pad/64
-    double *a3, *xw, *a4, *res, *xg, *bw;   // n_pad each (bw: rhs b, overwritten by w = L^-1 b)
-    double *scal;                // [0]=rr (sum res^2), [1]=sig_q (sum (g^2/2)/S), [2]=tau (sqrt tau2 of current row)
+    double *a3, *xw, *a4, *res, *xg, *bw;   // n_pad each (bw: right-hand side b = a1 - a3)
+    double *scal;                // [0]=rr (sum res^2), [1]=sig_q (sum (g^2/2)/S), [2]=tau (sqrt tau2 of current row), [3..4] pre-drawn tau2
+    double *Minv;                // R*R + 1: inv(M) and logdet M of the state the next k_node reads (written by k_tail)
     double *Psum;                // nblk_bp x (1+3R) partial sums from k_backproj
     int nblk_bp, chunk_bp;
-    long long *counters;         // [0] jitter, [1] nan_w, [2] sampler cap, [3] chol fail
+    long long *counters;         // [0] jitter, [1] nan_w, [2] sampler cap, [3] chol fail, [4..7] where, [8] branch-order violations
+    unsigned long long *dbg;     // in-kernel s_memtime stamps (diagnostics only; never read by any kernel)
+    unsigned int *stamp;         // one word per k_gram_reduce workgroup: iteration id of the Gram it finished (checked by k_chol_step)
 };
 
 enum { ROW_TAU2 = 0, ROW_THETA = 1, ROW_DELTA = 2, ROW_MU = 3 };
-enum { SC_RR = 0, SC_SIGQ = 1, SC_TAU = 2 };
+enum { SC_RR = 0, SC_SIGQ = 1, SC_TAU = 2, SC_TAU2N = 3, SC_TAU2N_IT = 4 };   // TAU2N: tau2 pre-drawn by k_tail for iteration id TAU2N_IT
 
 // ----------------------------------------------------------------------------------------- helpers
+// Sum over the 64 lanes of a wavefront, result in every lane.  Four DPP butterfly steps inside each row of 16 lanes
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) and a fixed-order sum of the four row totals through SGPRs
+// (v_readlane): no LDS permutes on the latency path, and a summation order that does not depend on the data.
+__device__ __forceinline__ double bnr_dpp_f64(double v, const int ctrl_sel)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (ctrl_sel == 0) { lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true); }
+    else if (ctrl_sel == 1) { lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true); }
+    else if (ctrl_sel == 2) { lo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true); }
+    else { lo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true); }
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bnr_readlane_c(double v, const int srclane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane), hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += bnr_dpp_f64(v, 0);
+    v += bnr_dpp_f64(v, 1);
+    v += bnr_dpp_f64(v, 2);
+    v += bnr_dpp_f64(v, 3);
+    return (bnr_readlane_c(v, 0) + bnr_readlane_c(v, 16)) + (bnr_readlane_c(v, 32) + bnr_readlane_c(v, 48));
+}
+// sum over each aligned group of 32 lanes (result in every lane of the group)
+__device__ __forceinline__ double half_wave_sum(double v)
+{
+    v += bnr_dpp_f64(v, 0);
+    v += bnr_dpp_f64(v, 1);
+    v += bnr_dpp_f64(v, 2);
+    v += bnr_dpp_f64(v, 3);
+    double lo = bnr_readlane_c(v, 0) + bnr_readlane_c(v, 16), hi = bnr_readlane_c(v, 32) + bnr_readlane_c(v, 48);
+    return ((threadIdx.x & 32) == 0) ? lo : hi;
 }
 __device__ __forceinline__ double block_sum(double v, double *sh /* >= blockDim/64 doubles */)
 {
@@ -100,11 +132,16 @@ __device__ inline int lds_chol(double *A, int R, int lane_in_block)
     }
     return 0;
 }
+__device__ __forceinline__ double bnr_readlane_u(double v, int srclane /* wave-uniform */)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane), hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
 // x (one value per lane, lane i < R holds b_i) <- L^-1 b ; column oriented, same operation order as a row sweep
 __device__ __forceinline__ double wave_fwd_solve(const double *L, int R, int lane, double b)
 {
     for (int k = 0; k < R; ++k) {
-        double xk = __shfl(b, k, 64) / L[k + R * k];
+        double xk = bnr_readlane_u(b, k) / L[k + R * k];
         if (lane == k) b = xk;
         else if (lane > k && lane < R) b = b - L[lane + R * k] * xk;
     }
@@ -114,7 +151,7 @@ __device__ __forceinline__ double wave_fwd_solve(const double *L, int R, int lan
 __device__ __forceinline__ double wave_bwd_solve_T(const double *L, int R, int lane, double b)
 {
     for (int k = R - 1; k >= 0; --k) {
-        double xk = __shfl(b, k, 64) / L[k + R * k];
+        double xk = bnr_readlane_u(b, k) / L[k + R * k];
         if (lane == k) b = xk;
         else if (lane < k) b = b - L[k + R * lane] * xk;
     }
@@ -130,14 +167,20 @@ __device__ __forceinline__ double edge_W(const double *u, const double *lam, int
 }
 
 // ===================================================================================== k_node
-// grid = V blocks, 64 threads (one wavefront per node).  mode bit0: draw tau2; bit1: node update.
-// update_tau2! (gibbs.jl:267-277): tau2 ~ InverseGamma(n/2 + V(V+1)/4, rr/2 + sig_q) from the carried sums.
+// grid = V blocks, 64 threads (one wavefront per node).  mode bit0: tau2 for this row is drawn (else read from the row);
+// bit1: node update; bit2: inv(M)/logdet M are recomputed here from row prev (test hooks) instead of read from cd.Minv.
+// update_tau2! (gibbs.jl:267-277): tau2 ~ InverseGamma(n/2 + V(V+1)/4, rr/2 + sig_q) from the carried sums; k_tail of the
+//   previous sweep has normally pre-drawn it (same draw site, same iteration id), otherwise it is drawn here.
 // update_u_xi! (gibbs.jl:293-371) for node k = blockIdx.x, all inputs from row prev (no Gauss-Seidel).  Weights in
 // log space (determinant lemma + Woodbury): log w_bot - log w_top = log(D/(1-D)) - 1/2[logdet M + logdet Sigma^-1]
 // + 1/2 b' Sigma b,  b = U'H^-1 gamma_k / tau2 -- equal to the reference's ratio of dense (V-1)-dim pdfs whenever
 // those do not under/overflow (gibbs.jl:349-351).
+// The V-1 other nodes are staged through LDS in chunks of 64 (one per lane: U_a = u_a .* lambda, V_a = U_a / h_a,
+// g_a / h_a), then lane p accumulates the p-th of the R(R+1)/2 + R sums sequentially over a (the reference's order).
+#define BNR_NODE_MAXSUM 9      // ceil((32*33/2 + 32) / 64)
 __global__ __launch_bounds__(64) void k_node(bnr_dev cd, int s, int mode)
 {
+    extern __shared__ double shn[];                           // 64 x (2R + 1): per staged node [U(R) | V(R) | g/h]
     __shared__ double sM[BNR_RMAX * BNR_RMAX], sMinv[BNR_RMAX * BNR_RMAX], sS[BNR_RMAX * BNR_RMAX], sL[BNR_RMAX * BNR_RMAX];
     __shared__ double slam[BNR_RMAX], sc[BNR_RMAX];
     const int lane = threadIdx.x, k = blockIdx.x, V = cd.V, R = cd.R;
@@ -147,9 +190,12 @@ __global__ __launch_bounds__(64) void k_node(bnr_dev cd, int s, int mode)
     int cap = 0;
     double tau2;
     if (mode & 1) {
-        double sigma = cd.scal[SC_RR] / 2.0 + cd.scal[SC_SIGQ];
-        double shape = (cd.n / 2.0) + (V * (V + 1) / 4.0);
-        tau2 = sigma / bnr_gamma(cd.seed, shape, P.it, SITE_TAU2, 0, &cap);
+        if (cd.scal[SC_TAU2N_IT] == (double)P.it) tau2 = cd.scal[SC_TAU2N];
+        else {
+            double sigma = cd.scal[SC_RR] / 2.0 + cd.scal[SC_SIGQ];
+            double shape = (cd.n / 2.0) + (V * (V + 1) / 4.0);
+            tau2 = sigma / bnr_gamma(cd.seed, shape, P.it, SITE_TAU2, 0, &cap);
+        }
         if (k == 0 && lane == 0) { row[ROW_TAU2] = tau2; cd.scal[SC_TAU] = sqrt(tau2); }
     } else {
         tau2 = row[ROW_TAU2];
@@ -160,46 +206,70 @@ __global__ __launch_bounds__(64) void k_node(bnr_dev cd, int s, int mode)
     const double Delta = prev[ROW_DELTA];
     const double *pu = prev + cd.o_u, *pg = prev + cd.o_gamma, *pS = prev + cd.o_S;
     if (lane < R) slam[lane] = prev[cd.o_lam + lane];
-    for (int i = lane; i < R * R; i += 64) sM[i] = prev[cd.o_M + i];
+    if (mode & 4) for (int i = lane; i < R * R; i += 64) sM[i] = prev[cd.o_M + i];
+    else for (int i = lane; i < R * R; i += 64) sMinv[i] = cd.Minv[i];
     __syncthreads();
 
-    // A[x,y] = sum_a U[a,x] U[a,y] / h_a ,  c[x] = sum_a U[a,x] g_a / h_a   over the V-1 other nodes
-    for (int x = 0; x < R; ++x) {
-        for (int y = x; y < R; ++y) {
-            double acc = 0.0;
-            for (int a = lane; a < V - 1; a += 64) {
-                int l = a < k ? a : a + 1;
-                int e = l > k ? bnr_edge_index(V, l, k) : bnr_edge_index(V, k, l);
-                acc += (pu[x + R * l] * slam[x]) * ((pu[y + R * l] * slam[y]) / pS[e]);
-            }
-            acc = wave_sum(acc);
-            if (lane == 0) { sS[x + R * y] = acc; sS[y + R * x] = acc; }
-        }
-        double acc = 0.0;
-        for (int a = lane; a < V - 1; a += 64) {
+    // which sums does this lane own: index p = lane + 64 m over pairs (x, y), y = x..R (y == R: the c_x sums)
+    const int W2 = 2 * R + 1, npair = R * (R + 1) / 2 + R;
+    int px[BNR_NODE_MAXSUM], py[BNR_NODE_MAXSUM];
+    double acc[BNR_NODE_MAXSUM];
+#pragma unroll
+    for (int m = 0; m < BNR_NODE_MAXSUM; ++m) {
+        int p = lane + 64 * m, x = 0;
+        acc[m] = 0.0;
+        if (p < npair) { int rem = p; while (rem >= R - x + 1) { rem -= R - x + 1; ++x; } px[m] = x; py[m] = x + rem; }
+        else { px[m] = 0; py[m] = 0; }
+    }
+    for (int a0 = 0; a0 < V - 1; a0 += 64) {
+        const int a = a0 + lane;
+        if (a < V - 1) {
             int l = a < k ? a : a + 1;
             int e = l > k ? bnr_edge_index(V, l, k) : bnr_edge_index(V, k, l);
-            acc += (pu[x + R * l] * slam[x]) * (pg[e] / pS[e]);
+            double h = pS[e], g = pg[e];
+            double *dst = shn + (size_t)lane * W2;
+            for (int x = 0; x < R; ++x) { double ux = pu[x + R * l] * slam[x]; dst[x] = ux; dst[R + x] = ux / h; }
+            dst[2 * R] = g / h;
         }
-        acc = wave_sum(acc);
-        if (lane == 0) sc[x] = acc;
+        __syncthreads();
+        const int na = min(64, V - 1 - a0);
+#pragma unroll
+        for (int m = 0; m < BNR_NODE_MAXSUM; ++m) {
+            if (lane + 64 * m < npair) {
+                const double *pa = shn + px[m], *pb = shn + R + py[m];
+                double t = acc[m];
+                for (int aa = 0; aa < na; ++aa) t += pa[(size_t)aa * W2] * pb[(size_t)aa * W2];
+                acc[m] = t;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < BNR_NODE_MAXSUM; ++m) {
+        if (lane + 64 * m < npair) {
+            if (py[m] == R) sc[px[m]] = acc[m];
+            else { sS[px[m] + R * py[m]] = acc[m]; sS[py[m] + R * px[m]] = acc[m]; }
+        }
     }
     __syncthreads();
 
-    // inv(M) and logdet M via Cholesky of M_prev (gibbs.jl:315)
-    for (int i = lane; i < R * R; i += 64) sL[i] = sM[i];
-    __syncthreads();
-    int fail = lds_chol(sL, R, lane);
-    double logdetM = 0.0;
-    for (int i = 0; i < R; ++i) logdetM += 2.0 * log(sL[i + R * i]);
-    // column j of inv(M): forward + backward solve of e_j
-    for (int j = 0; j < R; ++j) {
-        double b = (lane == j) ? 1.0 : 0.0;
-        b = wave_fwd_solve(sL, R, lane, b);
-        b = wave_bwd_solve_T(sL, R, lane, b);
-        if (lane < R) sMinv[lane + R * j] = b;
-    }
-    __syncthreads();
+    double logdetM;
+    int fail = 0;
+    if (mode & 4) {
+        // inv(M) and logdet M via Cholesky of M_prev (gibbs.jl:315)
+        for (int i = lane; i < R * R; i += 64) sL[i] = sM[i];
+        __syncthreads();
+        fail = lds_chol(sL, R, lane);
+        logdetM = 0.0;
+        for (int i = 0; i < R; ++i) logdetM += 2.0 * log(sL[i + R * i]);
+        for (int j = 0; j < R; ++j) {
+            double b = (lane == j) ? 1.0 : 0.0;
+            b = wave_fwd_solve(sL, R, lane, b);
+            b = wave_bwd_solve_T(sL, R, lane, b);
+            if (lane < R) sMinv[lane + R * j] = b;
+        }
+        __syncthreads();
+    } else logdetM = cd.Minv[R * R];
     // Sigma^-1 = A / tau2 + inv(M), Cholesky with the reference's jitter ladder (gibbs.jl:322-347)
     for (int i = lane; i < R * R; i += 64) sS[i] = sS[i] / tau2 + sMinv[i];
     __syncthreads();
@@ -224,7 +294,7 @@ __global__ __launch_bounds__(64) void k_node(bnr_dev cd, int s, int mode)
         }
     }
     if (fail || f2) {
-        if (lane == 0) atomicAdd((unsigned long long *)&cd.counters[3], 1ull);
+        if (lane == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[4], 1ull); }
         if (lane < R) row[cd.o_u + lane + R * k] = NAN;
         if (lane == 0) row[cd.o_xi + k] = NAN;
         return;
@@ -365,14 +435,20 @@ __global__ __launch_bounds__(1024) void k_gram(bnr_dev cd, int s)
         out[idx] = (sred[idx] + sred[BNR_GT * BNR_GT + idx]) + (sred[2 * BNR_GT * BNR_GT + idx] + sred[3 * BNR_GT * BNR_GT + idx]);
 }
 
-// G = sum_ks partial + I, lower tiles of the n_pad x n_pad column-major matrix.  grid = (lower tiles, 4), 256 threads.
-__global__ __launch_bounds__(256) void k_gram_reduce(bnr_dev cd)
+// E = extended matrix of the factorization, (2 n_pad + 32) x n_pad, column-major, leading dimension ldE:
+//     rows [0, n_pad)            G + I  (lower triangle)                      -> L
+//     rows [n_pad, 2 n_pad)      Y = I                                        -> L^-T   (back substitution becomes a GEMV)
+//     rows [2 n_pad, 2 n_pad+32) row 0 = b' (right-hand side), rest 0         -> w' = (L^-1 b)'  (forward substitution for free)
+// k_gram_reduce: G = sum_ks partial + I into the lower tiles of E, and Y = I.  grid = (lower tiles, 4), 256 threads.
+__host__ __device__ inline int bnr_ldE(int n_pad) { return 2 * n_pad + BNR_NB; }
+
+__global__ __launch_bounds__(256) void k_gram_reduce(bnr_dev cd, int s)
 {
     int t = blockIdx.x, ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     int tj = t - ti * (ti + 1) / 2;
     const int ntl = cd.ntile * (cd.ntile + 1) / 2;
-    const size_t ld = cd.n_pad, tsz = BNR_GT * BNR_GT;
+    const size_t ld = bnr_ldE(cd.n_pad), tsz = BNR_GT * BNR_GT;
     const int idx0 = blockIdx.y * (BNR_GT * BNR_GT / 4);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -381,25 +457,29 @@ __global__ __launch_bounds__(256) void k_gram_reduce(bnr_dev cd)
         for (int ks = 0; ks < cd.ksplit; ++ks) sacc += cd.Gpart[((size_t)ks * ntl + t) * tsz + idx];
         int i = ti * BNR_GT + idx % BNR_GT, j = tj * BNR_GT + idx / BNR_GT;
         if (i == j) sacc += 1.0;
-        cd.G[(size_t)i + ld * j] = sacc;
+        cd.E[(size_t)i + ld * j] = sacc;
     }
+    // Y = I (all n_pad x n_pad entries), spread over the whole grid
+    const int nwg = gridDim.x * gridDim.y, wg = blockIdx.x * gridDim.y + blockIdx.y, np = cd.n_pad;
+    for (size_t e = (size_t)wg * 256 + threadIdx.x; e < (size_t)np * np; e += (size_t)nwg * 256) {
+        int r = (int)(e % np), c = (int)(e / np);
+        cd.E[(size_t)(np + r) + ld * c] = (r == c) ? 1.0 : 0.0;
+    }
+    if (threadIdx.x == 0) cd.stamp[blockIdx.x * 4 + blockIdx.y] = cd.plan[cd.pbase[0] + s].it;
 }
 
 // ===================================================================================== blocked Cholesky + solve
 // (G + I) a4 = b,  b = a1 - a3  (gibbs.jl:434; the reference's generic `\` is an LU solve of this SPD system).
-// Right-looking blocked Cholesky, NB = 32, ONE launch per panel with lookahead 1 (k_chol_step(p), p = 0..nbk-1).
-// The matrix is extended by two kinds of extra rows that ride through the same sweeps:
-//     [ G + I ]  block rows 0..nbk-1        -> L
-//     [  b'   ]  one row                    -> w' = (L^-1 b)'          (the forward substitution, for free)
-//     [   I   ]  block rows 0..nbk-1        -> L^-T                    (so the back substitution becomes one GEMV)
-//   role A (panel workgroups): a block row first applies panel p-1's update to its blocks (p,p) and (i,p), then one
-//       wavefront sweeps the 64 x 32 register-resident panel [A_pp ; A_ip] column by column: pivot broadcast by
-//       v_readlane, rsqrt by v_rsq_f64 + 2 Newton steps, rank-1 updates by v_fma_f64 with the broadcast in SGPRs.
-//       Lanes 0-31 redo the diagonal block in every workgroup (no cross-workgroup hand-off inside a launch).
-//   role B (update workgroups): apply panel p-1's update to every block (.,j), j >= p+1.
-// Identity block row r is zero left of column block r, so it takes part from panel r on.  L^-T is stored transposed,
-// Winv = L^-1 column-major, so that row r of L^-T is the contiguous column r of Winv.
-// k_solve_gemv: a4 = L^-T w, then the n-vector bookkeeping for X gamma_new.
+// Right-looking blocked Cholesky of E, NB = 32, ONE launch per panel with lookahead 1 (k_chol_step(p), p = 0..nbk-1).
+// Every block row of E (matrix rows, identity rows, the b block) runs the same code:
+//   role A (nbk + 2 panel workgroups): apply panel p-1's update to the blocks (p,p) and (rho,p) by f64 MFMA (operands
+//       loaded from L2 straight in fragment layout), then ONE wavefront sweeps the 64 x 32 register-resident panel
+//       [E_pp ; E_rho,p] column by column: pivot broadcast by v_readlane, rsqrt = v_rsq_f64 + 2 Newton steps, rank-1 updates of
+//       the next two columns with v_readlane broadcasts, of the remaining columns one step later with LDS broadcast reads
+//       (software pipelined so that the LDS latency hides behind the next pivot's rsqrt chain).
+//       Lanes 0-31 redo the diagonal block in every workgroup: no cross-workgroup hand-off inside a launch.
+//   role B (update workgroups): E[rho,j] -= L[rho,p-1] L[j,p-1]' for every block column j >= p+1, by f64 MFMA.
+// k_solve_gemv: a4 = Y w, then the n-vector bookkeeping for X gamma_new.
 __device__ __forceinline__ double bnr_readlane(double v, int srclane)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -418,169 +498,162 @@ __device__ __forceinline__ double bnr_rsqrt(double x)
 }
 
 #define BNR_LP (BNR_NB + 1)
-// number of workgroups of launch p
-__host__ __device__ inline int bnr_chol_npanel(int nbk, int p) { return (nbk - p) + 1 + (p + 1); }
+__host__ __device__ inline int bnr_chol_npanel(int nbk, int p) { (void)p; return nbk + 2; }
 __host__ __device__ inline int bnr_chol_ntile(int nbk, int p)
 {
     if (p == 0) return 0;
     int m = nbk - (p + 1);
-    return m * (m + 1) / 2 + m + p * m;          // A tiles, b-row tiles, identity-row tiles (r <= p-1)
+    return m * (m + 1) / 2 + m * (p + 1);        // matrix tiles + (p identity block rows + the b block) per column
 }
 
-__global__ __launch_bounds__(256) void k_chol_step(bnr_dev cd, int p)
+// 16x16 tile of  C - A B'  over K = 32:  C[m][n], m <-> column, n <-> row (n = lane & 15 is contiguous in memory).
+//   colrows: &E[first column-side row, kc]   (the rows of L[j-block, p-1] that give the tile's 16 columns)
+//   rowrows: &E[first row-side row, kc]      (the rows of L[rho-block, p-1] that give the tile's 16 rows)
+__device__ __forceinline__ bnr_d4 bnr_tile_update(const double *colrows, const double *rowrows, size_t ld, int lane, bnr_d4 c)
 {
-    __shared__ double sD[BNR_NB * BNR_LP], sB[BNR_NB * BNR_LP], sLp[BNR_NB * BNR_LP], sLi[BNR_NB * BNR_LP];
-    const int tid = threadIdx.x, nbk = cd.n_pad / BNR_NB;
-    const size_t ld = cd.n_pad;
+    const int ln = lane & 15, lk = lane >> 4;
+    double av[8], bv[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        av[ks] = colrows[(size_t)ln + ld * (size_t)(4 * ks + lk)];
+        bv[ks] = rowrows[(size_t)ln + ld * (size_t)(4 * ks + lk)];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[ks], bv[ks], c, 0, 0, 0);
+    return c;
+}
+
+__global__ __launch_bounds__(256, 1) void k_chol_step(bnr_dev cd, int p, int s)
+{
+    __shared__ double sD[BNR_NB * BNR_LP], sB[BNR_NB * BNR_LP];
+    __shared__ double sCol[2][BNR_NB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nbk = cd.n_pad / BNR_NB;
+    const size_t ld = bnr_ldE(cd.n_pad);
     const int npanel = bnr_chol_npanel(nbk, p);
-    const int r = tid & 31, c0 = tid >> 5;                 // thread owns elements (r, c0 + 8 m), m = 0..3
-    const int pc = p * BNR_NB;
+    const int pc = p * BNR_NB, kc = pc - BNR_NB;
+    const int mt = wave >> 1, nt = wave & 1;               // this wave's 16x16 tile of a 32x32 block: columns mt, rows nt
+    const int ln = lane & 15, lq = lane >> 4;
+    double *E = cd.E;
     if ((int)blockIdx.x >= npanel) {
-        // ------------------------------------------------ role B: blk[.,j] -= blk[.,p-1] L[j,p-1]'
+        // ------------------------------------------------ role B: E[rho,j] -= L[rho,p-1] L[j,p-1]'
         const int m = nbk - (p + 1);
-        int t = blockIdx.x - npanel;
+        int t = blockIdx.x - npanel, rho, j;
         const int ntri = m * (m + 1) / 2;
-        const int kc = pc - BNR_NB;
-        if (t >= ntri && t < ntri + m) {
-            const int j = p + 1 + (t - ntri);              // b row
-            if (tid < BNR_NB) {
-                double acc = cd.bw[j * BNR_NB + tid];
-                for (int k = 0; k < BNR_NB; ++k) acc = fma(-cd.bw[kc + k], cd.G[(size_t)(j * BNR_NB + tid) + ld * (kc + k)], acc);
-                cd.bw[j * BNR_NB + tid] = acc;
-            }
-            return;
-        }
-        int i, j, ident;
         if (t < ntri) {
             int ti = 0;
             while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
             int tj = t - ti * (ti + 1) / 2;
-            i = p + 1 + ti; j = p + 1 + tj; ident = 0;
+            rho = p + 1 + ti; j = p + 1 + tj;
         } else {
-            t -= ntri + m;
-            i = t / m; j = p + 1 + t % m; ident = 1;       // identity block row i (<= p-1)
+            t -= ntri;
+            j = p + 1 + t / (p + 1);
+            int rr = t % (p + 1);
+            rho = (rr < p) ? nbk + rr : 2 * nbk;           // identity block row rr, or the b block
         }
+        double *cp = E + (size_t)(rho * BNR_NB + nt * 16 + ln) + ld * (size_t)(j * BNR_NB + mt * 16 + lq);
+        bnr_d4 c;
 #pragma unroll
-        for (int mm = 0; mm < 4; ++mm) {
-            int c = c0 + 8 * mm;
-            // Linv^T block (i, kc-block) is stored transposed in Winv: element (r,c) at Winv[(kc + c) + ld*(i*NB + r)]
-            sLi[r + BNR_LP * c] = ident ? cd.Winv[(size_t)(kc + c) + ld * (i * BNR_NB + r)] : cd.G[(size_t)(i * BNR_NB + r) + ld * (kc + c)];
-            sLp[r + BNR_LP * c] = cd.G[(size_t)(j * BNR_NB + r) + ld * (kc + c)];
-        }
-        __syncthreads();
-        if (!ident) {
+        for (int r = 0; r < 4; ++r) c[r] = cp[ld * (size_t)(4 * r)];
+        c = bnr_tile_update(E + (size_t)(j * BNR_NB + mt * 16) + ld * (size_t)kc, E + (size_t)(rho * BNR_NB + nt * 16) + ld * (size_t)kc, ld, lane, c);
 #pragma unroll
-            for (int mm = 0; mm < 4; ++mm) {
-                int c = c0 + 8 * mm;
-                double *dst = cd.G + (size_t)(i * BNR_NB + r) + ld * (j * BNR_NB + c);
-                double acc = *dst;
-#pragma unroll 8
-                for (int k = 0; k < BNR_NB; ++k) acc = fma(-sLi[r + BNR_LP * k], sLp[c + BNR_LP * k], acc);
-                *dst = acc;
-            }
-        } else {
-            // transposed store: thread owns (row c0 + 8 mm of the block, column r) so that stores are contiguous in r
-#pragma unroll
-            for (int mm = 0; mm < 4; ++mm) {
-                int rr2 = c0 + 8 * mm;                      // row of the (i,j) block
-                double *dst = cd.Winv + (size_t)(j * BNR_NB + r) + ld * (i * BNR_NB + rr2);   // element (rr2, r)
-                double acc = (p - 1 == i) ? 0.0 : *dst;     // first update of this identity row: the block starts at zero
-#pragma unroll 8
-                for (int k = 0; k < BNR_NB; ++k) acc = fma(-sLi[rr2 + BNR_LP * k], sLp[r + BNR_LP * k], acc);
-                *dst = acc;
-            }
-        }
+        for (int r = 0; r < 4; ++r) cp[ld * (size_t)(4 * r)] = c[r];
         return;
     }
     // ---------------------------------------------------- role A: panel workgroup
     const int b = blockIdx.x;
-    int kind, i;
-    if (b < nbk - p) { kind = 0; i = p + b; }              // block row i of G + I
-    else if (b == nbk - p) { kind = 1; i = 0; }            // b row
-    else { kind = 2; i = b - (nbk - p) - 1; }              // identity block row i (0..p)
-    const int kc = pc - BNR_NB;
+    if (p == 0 && b == 0) {
+        // cheap safety net for the two-branch schedule: every k_gram_reduce workgroup of THIS sweep must have finished
+        const unsigned int it = cd.plan[cd.pbase[0] + s].it;
+        const int nred = 4 * (cd.ntile * (cd.ntile + 1) / 2);
+        for (int w = tid; w < nred; w += blockDim.x)
+            if (cd.stamp[w] != it) atomicAdd((unsigned long long *)&cd.counters[8], 1ull);
+    }
+#ifdef BNR_STAMPS
+#define BNR_STAMP(slot) do { if (b == 0 && tid == 0) cd.dbg[p * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BNR_STAMP(slot) do { } while (0)
+#endif
+    BNR_STAMP(0);
+    int rho;                                               // own block row
+    if (b < nbk - p) rho = p + b;                          // matrix rows p..nbk-1
+    else if (b < nbk + 1) rho = nbk + (b - (nbk - p));     // identity block rows 0..p
+    else rho = 2 * nbk;                                    // the b block
+    {
+        const double *dp = E + (size_t)(pc + nt * 16 + ln) + ld * (size_t)(pc + mt * 16 + lq);
+        const double *bp = E + (size_t)(rho * BNR_NB + nt * 16 + ln) + ld * (size_t)(pc + mt * 16 + lq);
+        bnr_d4 cD, cB;
 #pragma unroll
-    for (int mm = 0; mm < 4; ++mm) {
-        int c = c0 + 8 * mm;
-        sD[r + BNR_LP * c] = cd.G[(size_t)(pc + r) + ld * (pc + c)];
-        double v;
-        if (kind == 0) v = cd.G[(size_t)(i * BNR_NB + r) + ld * (pc + c)];
-        else if (kind == 1) v = (r == 0) ? cd.bw[pc + c] : 0.0;
-        else v = (i == p) ? ((r == c) ? 1.0 : 0.0) : ((i == p - 1) ? 0.0 : cd.Winv[(size_t)(pc + c) + ld * (i * BNR_NB + r)]);
-        sB[r + BNR_LP * c] = v;
+        for (int r = 0; r < 4; ++r) { cD[r] = dp[ld * (size_t)(4 * r)]; cB[r] = bp[ld * (size_t)(4 * r)]; }
         if (p > 0) {
-            sLp[r + BNR_LP * c] = cd.G[(size_t)(pc + r) + ld * (kc + c)];
-            double w;
-            if (kind == 0) w = cd.G[(size_t)(i * BNR_NB + r) + ld * (kc + c)];
-            else if (kind == 1) w = (r == 0) ? cd.bw[kc + c] : 0.0;
-            else w = (i <= p - 1) ? cd.Winv[(size_t)(kc + c) + ld * (i * BNR_NB + r)] : 0.0;
-            sLi[r + BNR_LP * c] = w;
+            const double *colrows = E + (size_t)(pc + mt * 16) + ld * (size_t)kc;
+            cD = bnr_tile_update(colrows, E + (size_t)(pc + nt * 16) + ld * (size_t)kc, ld, lane, cD);
+            cB = bnr_tile_update(colrows, E + (size_t)(rho * BNR_NB + nt * 16) + ld * (size_t)kc, ld, lane, cB);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sD[(nt * 16 + ln) + BNR_LP * (mt * 16 + lq + 4 * r)] = cD[r];
+            sB[(nt * 16 + ln) + BNR_LP * (mt * 16 + lq + 4 * r)] = cB[r];
         }
     }
     __syncthreads();
-    if (p > 0) {
-        double accD[4], accB[4];
-#pragma unroll
-        for (int mm = 0; mm < 4; ++mm) {
-            int c = c0 + 8 * mm;
-            double d = sD[r + BNR_LP * c], bb = sB[r + BNR_LP * c];
-#pragma unroll 8
-            for (int k = 0; k < BNR_NB; ++k) {
-                double lpc = sLp[c + BNR_LP * k];
-                d = fma(-sLp[r + BNR_LP * k], lpc, d);
-                bb = fma(-sLi[r + BNR_LP * k], lpc, bb);
-            }
-            accD[mm] = d; accB[mm] = bb;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int mm = 0; mm < 4; ++mm) { int c = c0 + 8 * mm; sD[r + BNR_LP * c] = accD[mm]; sB[r + BNR_LP * c] = accB[mm]; }
-        __syncthreads();
-    }
-    if (tid < 64) {
+    BNR_STAMP(2);
+    if (wave == 0) {
         // panel sweep, lane = row: lanes 0..31 rows of the diagonal block, lanes 32..63 rows of the own block
-        const int lane = tid, rr = lane & 31;
+        const int rr = lane & 31;
         const double *src = (lane < 32) ? sD : sB;
         double a[BNR_NB];
 #pragma unroll
         for (int c = 0; c < BNR_NB; ++c) a[c] = src[rr + BNR_LP * c];
         int bad = 0;
+        double lprev = 0.0;
 #pragma unroll
         for (int j = 0; j < BNR_NB; ++j) {
+            // (A) issue the LDS broadcast reads for the lagged tail of column j-1: its entries k = j+2 .. NB-1
+            // (measured on gfx950: a ds_write is NOT ordered before later ds_reads of the same wave without this wait)
+            double tk[BNR_NB];
+            if (j >= 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = j + 2; k < BNR_NB; ++k) tk[k] = sCol[(j - 1) & 1][k];
+            }
+            // (B) pivot chain of column j
             double piv = bnr_readlane(a[j], j);
             if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
             double rinv = bnr_rsqrt(piv);
             double lj = a[j] * rinv;
             a[j] = lj;
+            // (C) the next two columns right away
+            if (j + 1 < BNR_NB) a[j + 1] = fma(-lj, bnr_readlane(lj, j + 1), a[j + 1]);
+            if (j + 2 < BNR_NB) a[j + 2] = fma(-lj, bnr_readlane(lj, j + 2), a[j + 2]);
+            // (D) publish column j of the diagonal block for the lagged tail
+            if (lane < 32) sCol[j & 1][lane] = lj;
+            // (E) lagged tail of column j-1
+            if (j >= 1) {
 #pragma unroll
-            for (int k = j + 1; k < BNR_NB; ++k) {
-                double lk = bnr_readlane(lj, k);
-                a[k] = fma(-lj, lk, a[k]);
+                for (int k = j + 2; k < BNR_NB; ++k) a[k] = fma(-lprev, tk[k], a[k]);
             }
+            lprev = lj;
         }
-        if (bad && lane == 0 && b == 0) atomicAdd((unsigned long long *)&cd.counters[3], 1ull);
-        double *dstl = (lane < 32) ? sD : sB;
+        if (bad && lane == 0 && b == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[7], 1ull); }
+        // hand the swept own block back through LDS (the factored diagonal block is not needed by anybody later)
+        if (lane >= 32) {
 #pragma unroll
-        for (int c = 0; c < BNR_NB; ++c) dstl[rr + BNR_LP * c] = (lane < 32 && c > rr) ? 0.0 : a[c];
+            for (int c = 0; c < BNR_NB; ++c) sB[rr + BNR_LP * c] = a[c];
+        }
     }
     __syncthreads();
-    if (kind == 0) {
+    BNR_STAMP(3);
+    // The factored diagonal block L_pp is needed by nobody after this launch and is NOT written back: every panel
+    // workgroup of this launch reads the unfactored block (p,p) whenever it happens to start.
+    if (rho != p) {
+        const int r = tid & 31, c0 = tid >> 5;
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) {
             int c = c0 + 8 * mm;
-            if (b == 0) cd.G[(size_t)(pc + r) + ld * (pc + c)] = sD[r + BNR_LP * c];
-            else cd.G[(size_t)(i * BNR_NB + r) + ld * (pc + c)] = sB[r + BNR_LP * c];
-        }
-    } else if (kind == 1) {
-        if (tid < BNR_NB) cd.bw[pc + tid] = sB[BNR_LP * tid];
-    } else {
-        // (L^-T)[i-block row rr2, p-block col r] -> Winv[(pc + r) + ld*(i*NB + rr2)]  (contiguous in r)
-#pragma unroll
-        for (int mm = 0; mm < 4; ++mm) {
-            int rr2 = c0 + 8 * mm;
-            cd.Winv[(size_t)(pc + r) + ld * (i * BNR_NB + rr2)] = sB[rr2 + BNR_LP * r];
+            E[(size_t)(rho * BNR_NB + r) + ld * (size_t)(pc + c)] = sB[r + BNR_LP * c];
         }
     }
+    BNR_STAMP(4);
 }
 
 // Right-hand side: finishes the GEMVs of k_xpass and forms b = a1 - a3 (gibbs.jl:432-434):
@@ -614,36 +687,58 @@ __global__ __launch_bounds__(256) void k_rhs(bnr_dev cd, int s)
         double z2 = (i < n) ? bnr_normal(cd.seed, P.it, SITE_G_Z2, (uint32_t)i, 0) : 0.0;
         double bb = (i < n) ? ((cd.y[i] - xw - mu) / tau - (xs + z2)) : 0.0;
         cd.xw[i] = xw; cd.a3[i] = xs;          // a3 buffer keeps X sz (without z2)
-        cd.bw[i] = bb; cd.res[i] = bb;         // bw is overwritten by w = L^-1 b; res keeps b
+        cd.bw[i] = bb;                         // b, kept for the bookkeeping after the solve
+    }
+}
+// scatters b' into the b block of E (after k_gram_reduce of the same sweep: E is rewritten there).  grid = n_pad/256.
+__global__ __launch_bounds__(256) void k_rhs_place(bnr_dev cd)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x, np = cd.n_pad;
+    const size_t ld = bnr_ldE(np);
+    if (c < np) {
+        cd.E[(size_t)(2 * np) + ld * c] = cd.bw[c];
+        for (int r = 1; r < BNR_NB; ++r) cd.E[(size_t)(2 * np + r) + ld * c] = 0.0;
     }
 }
 
-// a4 = L^-T w : a4_r = sum_{c >= r} Linv[c, r] w_c = <column r of Winv, w>   (one wavefront per row r), then
-//   X gamma_new = X W + tau X sz + tau G a4,  G a4 = b - a4   (no third pass over X).  grid = n_pad/4 blocks of 256.
+// a4 = L^-T w = Y w : a4_r = sum_{c >= block(r)} Y[r,c] w_c, then
+//   X gamma_new = X W + tau X sz + tau G a4,  G a4 = b - a4   (no third pass over X).
+// grid = nbk blocks (one per block row of Y), 256 threads = 32 rows x 8 column groups.
 __global__ __launch_bounds__(256) void k_solve_gemv(bnr_dev cd)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rrow = blockIdx.x * 4 + wave;
-    const size_t ld = cd.n_pad;
-    const double *col = cd.Winv + ld * (size_t)rrow;
-    const int cstart = (rrow / BNR_NB) * BNR_NB;       // Winv is lower triangular: entries c >= r (block granularity)
-    double acc = 0.0;
-    for (int cc = cstart + lane; cc < cd.n_pad; cc += 64) acc = fma(col[cc], cd.bw[cc], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) {
-        const double tau = cd.scal[SC_TAU];
-        double b = cd.res[rrow];
-        cd.a4[rrow] = acc;
-        cd.xg[rrow] = (rrow < cd.n) ? (cd.xw[rrow] + tau * cd.a3[rrow] + tau * (b - acc)) : 0.0;
+    extern __shared__ double shs[];                         // n_pad (w) + 8*32 partials
+    double *swv = shs, *spart = shs + cd.n_pad;
+    const int np = cd.n_pad, tid = threadIdx.x;
+    const size_t ld = bnr_ldE(np);
+    const int rb = blockIdx.x, rl = tid & 31, cg = tid >> 5;
+    const int cstart = rb * BNR_NB;
+    for (int c = cstart + tid; c < np; c += 256) swv[c] = cd.E[(size_t)(2 * np) + ld * c];
+    __syncthreads();
+    const double *yrow = cd.E + (size_t)(np + rb * BNR_NB + rl);
+    double acc0 = 0.0, acc1 = 0.0;
+    int c = cstart + cg;
+    for (; c + 8 < np; c += 16) { acc0 = fma(yrow[ld * (size_t)c], swv[c], acc0); acc1 = fma(yrow[ld * (size_t)(c + 8)], swv[c + 8], acc1); }
+    for (; c < np; c += 8) acc0 = fma(yrow[ld * (size_t)c], swv[c], acc0);
+    spart[cg * 32 + rl] = acc0 + acc1;
+    __syncthreads();
+    if (tid < 32) {
+        double a4 = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) a4 += spart[g * 32 + tid];
+        const int r = rb * BNR_NB + tid;
+        const double tau = cd.scal[SC_TAU], bb = cd.bw[r];
+        cd.a4[r] = a4;
+        cd.xg[r] = (r < cd.n) ? (cd.xw[r] + tau * cd.a3[r] + tau * (bb - a4)) : 0.0;
     }
 }
 
 // ===================================================================================== k_backproj
-// grid = nblk_bp blocks of 256 threads; block owns chunk_bp (<= 64) consecutive edges.
+// grid = nblk_bp blocks of 256 threads; block owns chunk_bp (<= 32) consecutive edges.
 // flags bit0: compute gamma (else read from row); bit1: draw S (else read from row); bit2: partial sums.
 //   gamma_e = W_e + tau (sz_e + S_prev,e x_e' a4)                           (gibbs.jl:435-436)
 //   S_e ~ GIG(1/2, chi = (gamma_e - W_e)^2 / tau2, psi = theta_prev)         (gibbs.jl:454-458, gig.jl)
 //   Psum[b][0] = sum_e S_e ; Psum[b][1+3r+c] = sum_e logpdf(Normal(W_c,e, sqrt(tau2 S_e)), gamma_e)  (gibbs.jl:603-605)
+// Back-projection x_e' a4: one wavefront per column, two columns in flight, a4 in LDS, DPP wave reduction.
 __global__ __launch_bounds__(256) void k_backproj(bnr_dev cd, int s, int flags)
 {
     extern __shared__ double sh[];          // n_pad (a4) + 64 (dots)
@@ -658,12 +753,15 @@ __global__ __launch_bounds__(256) void k_backproj(bnr_dev cd, int s, int flags)
     if (flags & 1) {
         for (int i = tid; i < cd.n_pad; i += blockDim.x) sa[i] = cd.a4[i];
         __syncthreads();
-        for (int t = wave; t < ne; t += 4) {
+        for (int t = wave; t < ne; t += 8) {
+            const int t2 = t + 4;
             const double *xc = cd.X + (size_t)(e0 + t) * ld;
-            double acc = 0.0;
-            for (int i = lane; i < cd.n_pad; i += 64) acc = fma(xc[i], sa[i], acc);
-            acc = wave_sum(acc);
-            if (lane == 0) sdot[t] = acc;
+            const double *xd = cd.X + (size_t)(e0 + (t2 < ne ? t2 : t)) * ld;
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll 4
+            for (int i = lane; i < cd.n_pad; i += 64) { double av = sa[i]; acc0 = fma(xc[i], av, acc0); acc1 = fma(xd[i], av, acc1); }
+            acc0 = wave_sum(acc0); acc1 = wave_sum(acc1);
+            if (lane == 0) { sdot[t] = acc0; if (t2 < ne) sdot[t2] = acc1; }
         }
     }
     __syncthreads();
@@ -710,70 +808,141 @@ __global__ __launch_bounds__(256) void k_backproj(bnr_dev cd, int s, int flags)
 
 // ===================================================================================== k_tail
 // One block of 1024 threads.  mask bits: 1 theta, 2 Delta, 4 M, 8 mu, 16 Lambda, 32 pi, 64 carried sums (res, rr,
-// sig_q for the next tau2), 128 ring wrap copy.  When a bit is clear the value already in `row` is kept.
-// xg_src: 0 = cd.xg (from k_solve); 1 = sum of the PG partials (X*gamma by k_xpass bit2).
+// sig_q for the next tau2), 128 ring wrap copy, 256 inv(M)/logdet M for the next k_node, 512 pre-draw the next tau2.
+// When a bit is clear the value already in `row` is kept.
+// xg_src: 0 = cd.xg (from k_solve_gemv); 1 = sum of the PG partials (X*gamma by k_xpass bit2).
+// Independent scalar draws are placed on different wavefronts so that their (long, scalar) sampler code runs concurrently.
 __global__ __launch_bounds__(1024) void k_tail(bnr_dev cd, int s, int mask, int xg_src)
 {
     __shared__ double sred[32];
     __shared__ double sPsi[BNR_RMAX * BNR_RMAX], sA[BNR_RMAX * BNR_RMAX], sT[BNR_RMAX * BNR_RMAX], sBm[BNR_RMAX * BNR_RMAX];
-    __shared__ double sll[3 * BNR_RMAX], slam[BNR_RMAX];
+    __shared__ double sll[3 * BNR_RMAX + 1], slam[BNR_RMAX], spi[3 * BNR_RMAX];
     __shared__ double sval[8];
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
+    if (P.wrap & 2) return;                      // placeholder entry in front of the first sweep of a run
     double *row = cd.trace + (size_t)P.row * cd.rowlen;
     const double *prev = cd.trace + (size_t)P.prev * cd.rowlen;
-    const int R = cd.R, V = cd.V, q = cd.q, n = cd.n, tid = threadIdx.x;
+    const int R = cd.R, V = cd.V, q = cd.q, n = cd.n, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const double tau2 = row[ROW_TAU2];
     int cap = 0;
     if (tid < R) slam[tid] = row[cd.o_lam + tid];
-    if (tid == 0) sval[1] = row[ROW_MU];
+    if (tid == 0) { sval[1] = row[ROW_MU]; sval[2] = 0.0; sval[3] = 0.0; }
 
-    // ---- reduce partial sums of k_backproj
+    // ---- phase 1: reductions.  Psum partials (32 lanes per output, fixed order); sum xi / #nonzero; sum(y - X gamma)
     if (mask & (1 | 16)) {
-        for (int j = tid; j < 1 + 3 * R; j += blockDim.x) {
-            double sacc = 0.0;
-            for (int b = 0; b < cd.nblk_bp; ++b) sacc += cd.Psum[(size_t)b * (1 + 3 * R) + j];
-            if (j == 0) sval[0] = sacc; else sll[j - 1] = sacc;
+        const int nout = 1 + 3 * R, j = tid >> 5, t = tid & 31;
+        for (int jj = j; jj < nout; jj += 32) {
+            double a = 0.0;
+            for (int b = t; b < cd.nblk_bp; b += 32) a += cd.Psum[(size_t)b * nout + jj];
+            a = half_wave_sum(a);
+            if (t == 0) sll[jj] = a;             // sll[0] = sum S, sll[1 + 3r + c] = log-likelihood sums
+        }
+    }
+    if ((mask & (8 | 64)) && xg_src == 1) {
+        for (int i = tid; i < cd.n_pad; i += blockDim.x) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int b = 0;
+            for (; b + 3 < cd.nblk_x; b += 4) {
+                a0 += cd.PG[(size_t)b * cd.n_pad + i]; a1 += cd.PG[(size_t)(b + 1) * cd.n_pad + i];
+                a2 += cd.PG[(size_t)(b + 2) * cd.n_pad + i]; a3 += cd.PG[(size_t)(b + 3) * cd.n_pad + i];
+            }
+            for (; b < cd.nblk_x; ++b) a0 += cd.PG[(size_t)b * cd.n_pad + i];
+            cd.xg[i] = (a0 + a1) + (a2 + a3);
         }
     }
     __syncthreads();
-    // ---- theta (gibbs.jl:476-479)
-    if ((mask & 1) && tid == 0) {
-        double g = bnr_gamma(cd.seed, cd.zeta + (V * (V + 1)) / 2.0, P.it, SITE_THETA, 0, &cap);
-        row[ROW_THETA] = g * (2.0 / (2.0 * cd.iota + sval[0]));
+    double sxi = 0.0, snz = 0.0, sres = 0.0;
+    if (mask & (2 | 4)) {
+        for (int v = tid; v < V; v += blockDim.x) { double x = row[cd.o_xi + v]; sxi += x; snz += (!(fabs(x) <= 0.1)) ? 1.0 : 0.0; }
+        sxi = block_sum(sxi, sred);
+        snz = block_sum(snz, sred);
     }
-    // ---- Delta (gibbs.jl:496-499, 130-140)
-    if (mask & 2) {
-        double sx = 0.0;
-        for (int v = tid; v < V; v += blockDim.x) sx += row[cd.o_xi + v];
-        sx = block_sum(sx, sred);
-        if (tid == 0) {
-            double a = cd.aDelta + sx, b = cd.bDelta + ((double)V - sx), out;
-            if (a > 0.0 && b > 0.0) {
-                double g1 = bnr_gamma(cd.seed, a, P.it, SITE_DELTA, 0, &cap), g2 = bnr_gamma(cd.seed, b, P.it, SITE_DELTA, 1, &cap);
-                out = g1 / (g1 + g2);
-            } else if (a > 0.0) out = 1.0;
-            else if (b > 0.0) out = 0.0;
-            else { double ua, ub; bnr_draw2(cd.seed, P.it, SITE_DELTA_COIN, 0, 0, ua, ub); out = (ua < 0.5) ? 0.0 : 1.0; }
-            row[ROW_DELTA] = out;
-        }
+    if (mask & 8) {
+        for (int i = tid; i < n; i += blockDim.x) sres += cd.y[i] - cd.xg[i];
+        sres = block_sum(sres, sred);
     }
-    // ---- M (gibbs.jl:516-547): Psi = I + sum_v u_v u_v', df = nu + #{xi != 0}, M ~ InverseWishart(df, Psi)
+    // ---- phase 2: Psi = I + sum_v u_v u_v' (gibbs.jl:516-525), sequential over v per entry (the reference's order)
+    const double df = cd.nu + snz;
     if (mask & 4) {
         const double *un = row + cd.o_u;
         for (int idx = tid; idx < R * R; idx += blockDim.x) {
             int a = idx % R, b = idx / R;
             double sacc = (a == b) ? 1.0 : 0.0;
+#pragma unroll 4
             for (int v = 0; v < V; ++v) sacc += un[a + R * v] * un[b + R * v];
             sPsi[idx] = sacc;
+            sA[idx] = sacc;
         }
-        double nz = 0.0;
-        for (int v = tid; v < V; v += blockDim.x) nz += (!(fabs(row[cd.o_xi + v]) <= 0.1)) ? 1.0 : 0.0;
-        nz = block_sum(nz, sred);
-        const double df = cd.nu + nz;
-        for (int idx = tid; idx < R * R; idx += blockDim.x) sA[idx] = sPsi[idx];     // sA <- C (chol of Psi)
-        __syncthreads();
+    }
+    __syncthreads();
+    // ---- phase 3: independent scalar draws on separate wavefronts
+    if (wave == 0 && lane == 0 && (mask & 1)) {                                  // theta (gibbs.jl:476-479)
+        double g = bnr_gamma(cd.seed, cd.zeta + (V * (V + 1)) / 2.0, P.it, SITE_THETA, 0, &cap);
+        row[ROW_THETA] = g * (2.0 / (2.0 * cd.iota + sll[0]));
+    }
+    if (wave == 1 && (mask & 2)) {                                               // Delta (gibbs.jl:496-499, 130-140)
+        double a = cd.aDelta + sxi, b = cd.bDelta + ((double)V - sxi);
+        double g = 0.0;
+        if (a > 0.0 && b > 0.0 && lane < 2) g = bnr_gamma(cd.seed, lane == 0 ? a : b, P.it, SITE_DELTA, (uint32_t)lane, &cap);
+        double g1 = bnr_readlane_c(g, 0), g2 = bnr_readlane_c(g, 1);
+        if (lane == 0) {
+            double out;
+            if (a > 0.0 && b > 0.0) out = g1 / (g1 + g2);
+            else if (a > 0.0) out = 1.0;
+            else if (b > 0.0) out = 0.0;
+            else { double ua, ub; bnr_draw2(cd.seed, P.it, SITE_DELTA_COIN, 0, 0, ua, ub); out = (ua < 0.5) ? 0.0 : 1.0; }
+            row[ROW_DELTA] = out;
+        }
+    }
+    if (wave == 2 && lane == 0 && (mask & 8)) {                                  // mu (gibbs.jl:565-570)
+        double m = sres / n + sqrt(tau2 / n) * bnr_normal(cd.seed, P.it, SITE_MU, 0, 0);
+        row[ROW_MU] = m; sval[1] = m;
+    }
+    if (wave == 3 && (mask & (16 | 32))) {                                       // Lambda then pi (gibbs.jl:586-636)
+        if ((mask & 16) && lane < R) {
+            int r = lane;
+            double l0 = sll[1 + 3 * r], l1 = sll[2 + 3 * r], l2 = sll[3 + 3 * r];
+            double pmax = fmax(l0, fmax(l1, l2));
+            double w0 = prev[cd.o_pi + r] * exp(l0 - pmax), w1 = prev[cd.o_pi + r + R] * exp(l1 - pmax), w2 = prev[cd.o_pi + r + 2 * R] * exp(l2 - pmax);
+            double ua, ub;
+            bnr_draw2(cd.seed, P.it, SITE_LAMBDA, (uint32_t)r, 0, ua, ub);
+            double lv = bnr_lambda_value(bnr_categorical3(w0, w1, w2, ua));
+            row[cd.o_lam + r] = lv; slam[r] = lv;
+        }
+        if (mask & 32) {
+            for (int t0 = 0; t0 < 3 * R; t0 += 64) {                             // wave-synchronous: slam written above by this wave
+                int t = t0 + lane;
+                if (t < 3 * R) {
+                    int r = t / 3, c = t % 3;
+                    double lam = slam[r];
+                    double base = pow((double)(r + 1), cd.eta);
+                    double alpha;
+                    if (lam == 1.0) alpha = (c == 0) ? base : (c == 1 ? 2.0 : 1.0);
+                    else if (lam == 0.0) alpha = (c == 0) ? base + 1.0 : 1.0;
+                    else alpha = (c == 0) ? base : (c == 1 ? 1.0 : 2.0);
+                    spi[t] = bnr_gamma(cd.seed, alpha, P.it, SITE_PI, (uint32_t)(3 * r + c), &cap);
+                }
+            }
+        }
+    }
+    if (wave >= 4 && (mask & 4)) {                                               // Bartlett factor entries (gibbs.jl:545)
+        for (int idx = tid - 256; idx < R * R; idx += blockDim.x - 256) {
+            int i = idx % R, j = idx / R;
+            double v = 0.0;
+            if (i == j) v = sqrt(2.0 * bnr_gamma(cd.seed, 0.5 * (df - j), P.it, SITE_M_CHI, (uint32_t)j, &cap));
+            else if (i > j) v = bnr_normal(cd.seed, P.it, SITE_M_N, (uint32_t)(i * R + j), 0);
+            sBm[idx] = v;
+        }
+    }
+    __syncthreads();
+    if ((mask & 32) && tid < 3 * R) {
+        int r = tid / 3, c = tid % 3;
+        row[cd.o_pi + r + R * c] = spi[tid] / (spi[3 * r] + spi[3 * r + 1] + spi[3 * r + 2]);
+    }
+    // ---- phase 4: M ~ InverseWishart(df, Psi) = (C A^-T)(C A^-T)', C = chol(Psi), A = Bartlett factor
+    if (mask & 4) {
         int f = lds_chol(sA, R, tid);
-        if (f) {                                                                      // retry ladder :529-543
+        if (f) {                                                                  // retry ladder :529-543
             if (tid == 0) atomicAdd((unsigned long long *)&cd.counters[0], 1ull);
             __syncthreads();
             for (int i = tid; i < R; i += blockDim.x) sPsi[i + R * i] += 1e-5;
@@ -781,18 +950,9 @@ __global__ __launch_bounds__(1024) void k_tail(bnr_dev cd, int s, int mask, int 
             for (int idx = tid; idx < R * R; idx += blockDim.x) sA[idx] = sPsi[idx];
             __syncthreads();
             f = lds_chol(sA, R, tid);
-            if (f && tid == 0) atomicAdd((unsigned long long *)&cd.counters[3], 1ull);
+            if (f && tid == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[5], 1ull); }
         }
         for (int idx = tid; idx < R * R; idx += blockDim.x) { int a = idx % R, b = idx / R; if (a < b) sA[idx] = 0.0; }
-        // Bartlett factor A -> sBm (lower): A_jj = sqrt(2 Gamma((df-j)/2)), A_ij ~ N(0,1) i > j
-        for (int idx = tid; idx < R * R; idx += blockDim.x) {
-            int i = idx % R, j = idx / R;
-            double v = 0.0;
-            if (i == j) v = sqrt(2.0 * bnr_gamma(cd.seed, 0.5 * (df - j), P.it, SITE_M_CHI, (uint32_t)j, &cap));
-            else if (i > j) v = bnr_normal(cd.seed, P.it, SITE_M_N, (uint32_t)(i * R + j), 0);
-            sBm[idx] = v;
-        }
-        __syncthreads();
         // T = A^-1 (lower): column j by thread j
         if (tid < R) {
             int j = tid;
@@ -808,76 +968,51 @@ __global__ __launch_bounds__(1024) void k_tail(bnr_dev cd, int s, int mask, int 
             }
         }
         __syncthreads();
-        // B = C T' -> sPsi ; M = B B'
-        for (int idx = tid; idx < R * R; idx += blockDim.x) {
+        for (int idx = tid; idx < R * R; idx += blockDim.x) {                     // B = C T' -> sPsi
             int a = idx % R, b = idx / R;
             double sacc = 0.0;
             for (int k = 0; k < R; ++k) sacc += sA[a + R * k] * sT[b + R * k];
             sPsi[idx] = sacc;
         }
         __syncthreads();
-        for (int idx = tid; idx < R * R; idx += blockDim.x) {
+        for (int idx = tid; idx < R * R; idx += blockDim.x) {                     // M = B B'
             int a = idx % R, b = idx / R;
             double sacc = 0.0;
             for (int k = 0; k < R; ++k) sacc += sPsi[a + R * k] * sPsi[b + R * k];
             row[cd.o_M + idx] = sacc;
-        }
-    }
-    // ---- X gamma_new
-    if ((mask & (8 | 64)) && xg_src == 1) {
-        for (int i = tid; i < cd.n_pad; i += blockDim.x) {
-            double sacc = 0.0;
-            for (int b = 0; b < cd.nblk_x; ++b) sacc += cd.PG[(size_t)b * cd.n_pad + i];
-            cd.xg[i] = sacc;
+            sBm[idx] = sacc;
         }
         __syncthreads();
+    } else if (mask & 256) {
+        for (int idx = tid; idx < R * R; idx += blockDim.x) sBm[idx] = row[cd.o_M + idx];
+        __syncthreads();
     }
-    // ---- mu (gibbs.jl:565-570)
-    if (mask & 8) {
-        double sacc = 0.0;
-        for (int i = tid; i < n; i += blockDim.x) sacc += cd.y[i] - cd.xg[i];
-        sacc = block_sum(sacc, sred);
-        if (tid == 0) { double m = sacc / n + sqrt(tau2 / n) * bnr_normal(cd.seed, P.it, SITE_MU, 0, 0); row[ROW_MU] = m; sval[1] = m; }
+    // ---- phase 5: inv(M) and logdet M for the next update_u_xi! (gibbs.jl:315), by Cholesky of M
+    if (mask & 256) {
+        for (int idx = tid; idx < R * R; idx += blockDim.x) sA[idx] = sBm[idx];
+        __syncthreads();
+        int f = lds_chol(sA, R, tid);
+        if (f && tid == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[6], 1ull); }
+        if (wave == 0) {
+            double ld = 0.0;
+            for (int i = 0; i < R; ++i) ld += 2.0 * log(sA[i + R * i]);
+            for (int j = 0; j < R; ++j) {
+                double b = (lane == j) ? 1.0 : 0.0;
+                b = wave_fwd_solve(sA, R, lane, b);
+                b = wave_bwd_solve_T(sA, R, lane, b);
+                if (lane < R) cd.Minv[lane + R * j] = b;
+            }
+            if (lane == 0) cd.Minv[R * R] = ld;
+        }
     }
-    // ---- Lambda (gibbs.jl:586-613)
-    if ((mask & 16) && tid < R) {
-        int r = tid;
-        double l0 = sll[3 * r], l1 = sll[3 * r + 1], l2 = sll[3 * r + 2];
-        double pmax = fmax(l0, fmax(l1, l2));
-        double w0 = prev[cd.o_pi + r] * exp(l0 - pmax), w1 = prev[cd.o_pi + r + R] * exp(l1 - pmax), w2 = prev[cd.o_pi + r + 2 * R] * exp(l2 - pmax);
-        double ua, ub;
-        bnr_draw2(cd.seed, P.it, SITE_LAMBDA, (uint32_t)r, 0, ua, ub);
-        double lv = bnr_lambda_value(bnr_categorical3(w0, w1, w2, ua));
-        row[cd.o_lam + r] = lv; slam[r] = lv;
-    }
-    __syncthreads();
-    // ---- pi (gibbs.jl:630-636, 159-169)
-    if ((mask & 32) && tid < 3 * R) {
-        int r = tid / 3, c = tid % 3;
-        double lam = slam[r];
-        double base = pow((double)(r + 1), cd.eta);
-        double alpha;
-        if (lam == 1.0) alpha = (c == 0) ? base : (c == 1 ? 2.0 : 1.0);
-        else if (lam == 0.0) alpha = (c == 0) ? base + 1.0 : 1.0;
-        else alpha = (c == 0) ? base : (c == 1 ? 1.0 : 2.0);
-        double g = bnr_gamma(cd.seed, alpha, P.it, SITE_PI, (uint32_t)(3 * r + c), &cap);
-        sT[tid] = g;
-    }
-    __syncthreads();
-    if ((mask & 32) && tid < 3 * R) {
-        int r = tid / 3, c = tid % 3;
-        double ssum = sT[3 * r] + sT[3 * r + 1] + sT[3 * r + 2];
-        row[cd.o_pi + r + R * c] = sT[tid] / ssum;
-    }
-    __syncthreads();
-    // ---- carried sums for the next update_tau2! (gibbs.jl:270-273): res = y - mu - X gamma, rr = res'res,
-    //      sig_q = sum_e ((gamma_e - W(u,lam)_e)^2 / 2) / S_e  with the NEW lambda
+    // ---- phase 6: carried sums for the next update_tau2! (gibbs.jl:270-273): res = y - mu - X gamma, rr = res'res,
+    //      sig_q = sum_e ((gamma_e - W(u,lam)_e)^2 / 2) / S_e  with the NEW lambda; optionally pre-draw the next tau2
     if (mask & 64) {
+        __syncthreads();
         const double mu = sval[1];
         double racc = 0.0;
         for (int i = tid; i < cd.n_pad; i += blockDim.x) {
             double rv = (i < n) ? (cd.y[i] - mu - cd.xg[i]) : 0.0;
-            cd.res[i] = rv;
             racc += rv * rv;
         }
         racc = block_sum(racc, sred);
@@ -888,19 +1023,28 @@ __global__ __launch_bounds__(1024) void k_tail(bnr_dev cd, int s, int mask, int 
             qacc += ((g * g) / 2.0) / row[cd.o_S + e];
         }
         qacc = block_sum(qacc, sred);
-        if (tid == 0) { cd.scal[SC_RR] = racc; cd.scal[SC_SIGQ] = qacc; }
+        if (tid == 0) {
+            cd.scal[SC_RR] = racc; cd.scal[SC_SIGQ] = qacc;
+            if (mask & 512) {
+                double sigma = racc / 2.0 + qacc;
+                double shape = (n / 2.0) + (V * (V + 1) / 4.0);
+                cd.scal[SC_TAU2N] = sigma / bnr_gamma(cd.seed, shape, P.it + 1u, SITE_TAU2, 0, &cap);
+                cd.scal[SC_TAU2N_IT] = (double)(P.it + 1u);
+            } else cd.scal[SC_TAU2N_IT] = -1.0;
+        }
     }
     // ---- purge ring (gibbs.jl:857-860): copy_table!(state, 1, j)
-    if ((mask & 128) && P.wrap) {
+    if ((mask & 128) && (P.wrap & 1)) {
         __syncthreads();
         double *dst = cd.trace;
         for (int i = tid; i < cd.rowlen; i += blockDim.x) dst[i] = row[i];
     }
-    if (cap && tid == 0) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
+    if (cap) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
 }
 
 // advances the plan base after a batch of sweeps (last node of the captured graph)
 __global__ void k_advance(int *pbase, int by) { if (threadIdx.x == 0 && blockIdx.x == 0) pbase[0] += by; }
+__global__ void k_setbase(int *pbase, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) pbase[0] = v; }
 
 // ===================================================================================== k_init_prior
 // initialize_variables! (gibbs.jl:191-224) into row 0.  One block of 256 threads.

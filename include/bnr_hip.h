@@ -131,6 +131,11 @@ int bnr_chain_counters(bnr_chain *chain, int64_t out[8]);
 int bnr_chain_set_profiling(bnr_chain *chain, int32_t enable);
 int bnr_chain_last_timing(bnr_chain *chain, int32_t which, double *avg_us, int64_t *launches);
 
+/* diagnostics: in-kernel cycle stamps of a -DBNR_STAMPS build (zeros otherwise) */
+int bnr_chain_debug_read(bnr_chain *chain, uint64_t *out, int32_t count);
+/* diagnostics: copy an internal work buffer to the host (0 = factorization matrix E, 1 = rhs b, 2 = a4, 3 = Gram partials) */
+int bnr_chain_debug_copy(bnr_chain *chain, int32_t which, double *out, int64_t count);
+
 /* tunables (performance only; never change results): name = "gram_ksplit", "graph", "overlap" ... */
 int bnr_chain_set_option(bnr_chain *chain, const char *name, int64_t value);
 

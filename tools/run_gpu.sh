@@ -13,4 +13,4 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -o $tag -- python3 $R/bench.py --steps 200 --warmup 24 --no-cpu-baseline > $R/gpurun_out/prof_$tag.log 2>&1; echo "prof exit=$?"
 cd $R && python tools/prof_summary.py gpurun_out/prof_$tag > gpurun_out/prof_${tag}_summary.txt; cat gpurun_out/prof_${tag}_summary.txt
-rm -f gpurun_out/prof_$tag/*/*kernel_trace.csv gpurun_out/prof_$tag/*kernel_trace.csv
+
