@@ -54,6 +54,7 @@ _SIGS = {
     "bnr_chain_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "bnr_chain_debug_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32]),
     "bnr_chain_debug_copy": (C.c_int, [C.c_void_p, C.c_int32, _dp, C.c_int64]),
+    "bnr_chain_debug_time_gram": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "bnr_host_philox": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "bnr_host_uniform2": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
     "bnr_host_normal": (C.c_double, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -230,6 +231,11 @@ class Chain:
         out = (C.c_uint64 * count)()
         check(self.L.bnr_chain_debug_read(self.h, out, count))
         return np.array(out[:], dtype=np.uint64)
+
+    def debug_time_gram(self, reps=100):
+        us = C.c_double(0)
+        check(self.L.bnr_chain_debug_time_gram(self.h, reps, C.byref(us)))
+        return us.value
 
     def debug_copy(self, which, count):
         out = np.empty(count)

@@ -121,9 +121,23 @@ int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const dou
     d.n_pad = round_up(n, BNR_GT);
     d.ntile = d.n_pad / BNR_GT;
     const int ntl = d.ntile * (d.ntile + 1) / 2;
-    // split K so that the Gram launch has >= ~256 workgroups (one per CU); each slice a multiple of 16 columns
-    d.ksplit = std::max(1, std::min((256 + ntl - 1) / ntl, (d.q + 63) / 64));
-    int kchunk = round_up((d.q + d.ksplit - 1) / d.ksplit, 16);
+    // split K so that the Gram launch fills the chip in whole rounds of one 1024-thread workgroup per CU: a grid of
+    // 288 workgroups on 256 CUs runs two rounds and takes twice as long as one of 252 (measured: 58 vs 31 us)
+    {
+        hipDeviceProp_t prop;
+        int ncu = 256;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        double best = -1.0;
+        d.ksplit = 1;
+        for (int ks = 1; ks <= 16; ++ks) {
+            if (ks > 1 && (d.q + ks - 1) / ks < 128) break;                 // keep every K slice at least 128 columns
+            long tasks = (long)ntl * ks;
+            double eff = (double)tasks / (double)(((tasks + ncu - 1) / ncu) * ncu);
+            double score = eff - 0.01 * ks;                                   // fewer split-K partials when efficiency ties
+            if (score > best) { best = score; d.ksplit = ks; }
+        }
+    }
+    int kchunk = round_up((d.q + d.ksplit - 1) / d.ksplit, 32);
     d.q_pad = kchunk * d.ksplit;
     // row layout
     int o = 4;
@@ -153,7 +167,7 @@ int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const dou
 #define TRY(x) do { rc = (x); if (rc) { bnr_chain_destroy(c); return rc; } } while (0)
     TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess ? BNR_OK : fail(BNR_ERR_HIP, "hipStreamCreate failed"));
     TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess ? BNR_OK : fail(BNR_ERR_HIP, "hipStreamCreate failed"));
-    TRY(dev_alloc(c, &Xd, (size_t)d.n_pad * d.q_pad));
+    TRY(dev_alloc(c, &Xd, (size_t)d.n_pad * (d.q_pad + 64)));       // + 64 zero columns: the Gram prefetch may run 5 batches past a slice
     TRY(dev_alloc(c, &yd, d.n_pad));
     TRY(dev_alloc(c, &ek, d.q));
     TRY(dev_alloc(c, &el, d.q));
@@ -166,6 +180,26 @@ int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const dou
         for (int k = 0; k < V; ++k) for (int l = k; l < V; ++l, ++e) { hk[e] = k; hl[e] = l; }
         hipMemcpy(ek, hk.data(), d.q * sizeof(int), hipMemcpyHostToDevice);
         hipMemcpy(el, hl.data(), d.q * sizeof(int), hipMemcpyHostToDevice);
+    }
+    {
+        // XCD-aware task map of k_gram (tasks = lower tiles x K slices)
+        const int ntask = ntl * d.ksplit;
+        std::vector<int> map(ntask, -1), next_tile(d.ksplit, 0);
+        std::vector<int> later;
+        for (int i = 0; i < ntask; ++i) {
+            int x = i % 8;
+            if (x < d.ksplit && next_tile[x] < ntl) { map[i] = next_tile[x] | (x << 16); next_tile[x]++; }
+            else later.push_back(i);
+        }
+        int ks = 0;
+        for (int i : later) {
+            while (ks < d.ksplit && next_tile[ks] >= ntl) ++ks;
+            map[i] = next_tile[ks] | (ks << 16); next_tile[ks]++;
+        }
+        int *gm = nullptr;
+        TRY(dev_alloc(c, &gm, ntask));
+        hipMemcpy(gm, map.data(), ntask * sizeof(int), hipMemcpyHostToDevice);
+        d.gmap = gm;
     }
     d.X = Xd; d.y = yd; d.ek = ek; d.el = el;
     TRY(alloc_trace(c, tot_save, &d.trace));
@@ -268,7 +302,7 @@ static void launch_gram(bnr_chain *c, int s, hipStream_t st, bool timed)
         e0 = c->ev[2 * s]; e1 = c->ev[2 * s + 1];
         hipEventRecord(e0, st);
     }
-    hipLaunchKernelGGL(k_gram, dim3(ntl, d.ksplit), dim3(1024), 0, st, c->d, s);
+    hipLaunchKernelGGL(k_gram, dim3(ntl * d.ksplit), dim3(1024), 0, st, c->d, s);
     if (timed) hipEventRecord(e1, st);
     hipLaunchKernelGGL(k_gram_reduce, dim3(ntl, 4), dim3(256), 0, st, c->d, s);
 }
@@ -285,7 +319,7 @@ static void launch_solve(bnr_chain *c)
 static void launch_backproj(bnr_chain *c, int s, int flags)
 { hipLaunchKernelGGL(k_backproj, dim3(c->d.nblk_bp), dim3(256), (c->d.n_pad + 64) * sizeof(double), c->stream, c->d, s, flags); }
 static void launch_tail(bnr_chain *c, int s, int mask, int xg_src)
-{ hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), 0, c->stream, c->d, s, mask, xg_src); }
+{ hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), (size_t)c->d.R * c->d.V * sizeof(double), c->stream, c->d, s, mask, xg_src); }
 static hipEvent_t next_event(bnr_chain *c)
 {
     if (c->fj_next >= c->fj.size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); c->fj.push_back(e); }
@@ -824,6 +858,33 @@ int bnr_chain_debug_copy(bnr_chain *c, int32_t which, double *out, int64_t count
     const double *src = which == 0 ? c->d.E : (which == 1 ? c->d.bw : (which == 2 ? c->d.a4 : c->d.Gpart));
     HIPCHK(hipMemcpy(out, src, sizeof(double) * count, hipMemcpyDeviceToHost));
     return BNR_OK;
+}
+
+int bnr_chain_debug_time_gram(bnr_chain *c, int32_t reps, double *avg_us)
+{
+    if (!c || !avg_us || reps < 1) return fail(BNR_ERR_BAD_ARG, "bad argument");
+    int gridsz = 0;
+    if (reps >= 1000000) { gridsz = reps / 1000000; reps = reps % 1000000; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->plan_pin[0] = bnr_plan_entry{1u, 1, 0, 0};
+    int rc = upload_plan(c, 1);
+    if (rc) return rc;
+    const bnr_dev &d = c->d;
+    const int ntl = d.ntile * (d.ntile + 1) / 2;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k_gram, dim3(ntl * d.ksplit), dim3(1024), 0, c->stream, c->d, 0);
+    hipEventRecord(e0, c->stream);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_gram, dim3(gridsz ? gridsz : ntl * d.ksplit), dim3(1024), 0, c->stream, c->d, 0);
+    hipEventRecord(e1, c->stream);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *avg_us = 1e3 * ms / reps;
+    c->carried_row = -1;
+    return check_launch("debug_time_gram");
 }
 
 int bnr_chain_set_profiling(bnr_chain *c, int32_t enable)

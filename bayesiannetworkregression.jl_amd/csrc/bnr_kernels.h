@@ -47,6 +47,7 @@ struct bnr_dev {
     int nblk_x, chunk_x;
     double *Gpart, *E;           // Gram partial tiles; E = extended matrix of the factorization (see k_gram_reduce)
     int ksplit, ntile;           // ntile = n_pad/64
+    const int *gmap;             // k_gram: workgroup id -> (tile | ks << 16), XCD-aware (K slice x on the workgroups of XCD label x)
     double *a3, *xw, *a4, *res, *xg, *bw;   // n_pad each (bw: right-hand side b = a1 - a3)
     double *scal;                // [0]=rr (sum res^2), [1]=sig_q (sum (g^2/2)/S), [2]=tau (sqrt tau2 of current row), [3..4] pre-drawn tau2
     double *Minv;                // R*R + 1: inv(M) and logdet M of the state the next k_node reads (written by k_tail)
@@ -384,40 +385,107 @@ __global__ __launch_bounds__(256) void k_xpass(bnr_dev cd, int s, int which)
 // profiles/round1_mfma_f64_peak.txt), hence 4 waves per SIMD and the in-workgroup K split, reduced through LDS.
 // blockIdx.y = K slice across workgroups (split-K partials, summed by k_gram_reduce).
 typedef double bnr_d4 __attribute__((ext_vector_type(4)));
+typedef double bnr_d2 __attribute__((ext_vector_type(2)));
 #define BNR_GRAM_KG 4
+#define BNR_GRAM_KB 8                 // columns of X per staged batch (2 MFMA k-steps)
+#define BNR_GRAM_CS 80                // LDS column stride in doubles: 64 rows + 16 pad -> conflict-free ds_read_b64 fragments
 
+// LDS-staged, double-buffered K loop.  Per K-group (4 waves = 256 threads) and batch: the j-side panel X[j-rows, 8 cols]
+// and the S-scaled i-side panel are loaded one batch ahead with coalesced 16-byte global loads (registers), written to
+// LDS [col][row] with a padded column stride, and read back as MFMA fragments with ds_read_b64.
 __global__ __launch_bounds__(1024) void k_gram(bnr_dev cd, int s)
 {
-    __shared__ double sred[BNR_GRAM_KG * BNR_GT * BNR_GT];     // 128 KiB: one 64x64 tile per K-group
+    __shared__ double sred[BNR_GRAM_KG * BNR_GT * BNR_GT];     // 128 KiB: staging buffers during the loop, then the K-group reduction
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     const double *Sp = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
-    int t = blockIdx.x, ti = 0;
+    // workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD); the host-built map gives the
+    // workgroups of one XCD the same K slice, so that slice of X (~3 MB) stays in that XCD's 4 MB L2.  Speed only.
+#ifdef BNR_STAMPS
+#define BNR_GSTAMP(slot) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 251)) { int o_ = 400 + 8 * (blockIdx.x == 0 ? 0 : (blockIdx.x == 100 ? 1 : 2)) + (slot); cd.dbg[o_] = __builtin_amdgcn_s_memtime(); cd.dbg[o_ + 4] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define BNR_GSTAMP(slot) do { } while (0)
+#endif
+    BNR_GSTAMP(0);
+#ifdef BNR_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 256) { cd.dbg[512 + blockIdx.x] = __builtin_amdgcn_s_memrealtime(); unsigned xcc = __builtin_amdgcn_s_getreg((20 | (0 << 6) | (3 << 11))); unsigned hwid = __builtin_amdgcn_s_getreg((4 | (0 << 6) | (31 << 11))); cd.dbg[256 + blockIdx.x] = ((unsigned long long)xcc << 32) | hwid; }
+#endif
+    const int task = cd.gmap[blockIdx.x];
+    int t = task & 0xFFFF, ti = 0;
+    const int ks = task >> 16;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     int tj = t - ti * (ti + 1) / 2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kg = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
-    const int i0 = ti * BNR_GT + wi * 32, j0 = tj * BNR_GT + wj * 32;
-    const int ks = blockIdx.y;
-    const int kchunk = cd.q_pad / cd.ksplit;          // multiple of 16 (host guarantees)
-    const int ksub = kchunk / BNR_GRAM_KG;            // multiple of 4
-    const int eb = ks * kchunk + kg * ksub, ee = eb + ksub;
+    const int kchunk = cd.q_pad / cd.ksplit;          // multiple of 32 (host guarantees)
+    const int ksub = kchunk / BNR_GRAM_KG;            // multiple of 8
+    const int eb = ks * kchunk + kg * ksub;
+    const int nbatch = ksub / BNR_GRAM_KB;
     const size_t ld = cd.n_pad;
     const int li = lane & 15, lk = lane >> 4;
-    const double *xi = cd.X + (size_t)(i0 + li) + (size_t)(eb + lk) * ld;
-    const double *xj = cd.X + (size_t)(j0 + li) + (size_t)(eb + lk) * ld;
+    // staging: this thread moves rows (2 rp, 2 rp + 1) of column c of both panels.  Addresses = wave-uniform base of the
+    // batch (SGPRs, advanced by scalar adds) + a per-lane offset that never changes: no vector address arithmetic in the loop
+    const int tg = threadIdx.x & 255, c = tg >> 5, rp = tg & 31;
+    const size_t offI = (size_t)(ti * BNR_GT + 2 * rp) + (size_t)c * ld, offJ = (size_t)(tj * BNR_GT + 2 * rp) + (size_t)c * ld;
+    const double *xb = cd.X + (size_t)eb * ld;                         // uniform: first column of this K-group
+    const double *sb = Sp + eb;                                        // uniform (columns >= q hold zeros in X: any finite S is fine)
+    const int smax = cd.q - 1 - eb;                                    // clamp for the S index
+    const int PANEL = BNR_GRAM_KB * BNR_GRAM_CS;                       // doubles per panel
+    double *stg = sred + (size_t)kg * (4 * PANEL);                     // [buf][I|J][col][row]
+    const int woff = c * BNR_GRAM_CS + 2 * rp;
     bnr_d4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};   // c[jt][it]
-#pragma unroll 4
-    for (int e = eb; e < ee; e += 4) {
-        int ecol = e + lk;
-        double sv = (ecol < cd.q) ? Sp[ecol] : 0.0;
-        double a0 = xj[0], a1 = xj[16];
-        double b0 = xi[0] * sv, b1 = xi[16] * sv;
-        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
-        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
-        xi += 4 * ld; xj += 4 * ld;
+    // register prefetch two batches deep, loop unrolled by two so that the register sets alternate without moves
+    bnr_d2 riA, rjA, riB, rjB;
+    double svA, svB;
+#define BNR_GRAM_LOAD(RI, RJ, SV, BIDX)                                                                   \
+    do {                                                                                                  \
+        const double *cb_ = xb + (size_t)(BIDX) * (BNR_GRAM_KB * ld);                                     \
+        int si_ = (BIDX) * BNR_GRAM_KB + c;                                                               \
+        SV = sb[si_ < smax ? si_ : smax];                                                                 \
+        RI = *(const bnr_d2 *)(cb_ + offI);                                                               \
+        RJ = *(const bnr_d2 *)(cb_ + offJ);                                                               \
+    } while (0)
+#define BNR_GRAM_STORE(RI, RJ, SV, BUF)                                                                   \
+    do {                                                                                                  \
+        double *nx_ = stg + (size_t)(BUF) * (2 * PANEL);                                                  \
+        *(bnr_d2 *)(nx_ + woff) = RI * SV;                                                                \
+        *(bnr_d2 *)(nx_ + PANEL + woff) = RJ;                                                             \
+    } while (0)
+#define BNR_GRAM_COMPUTE(BUF)                                                                             \
+    do {                                                                                                  \
+        const double *bufI = stg + (size_t)(BUF) * (2 * PANEL), *bufJ = bufI + PANEL;                     \
+        _Pragma("unroll") for (int k2 = 0; k2 < BNR_GRAM_KB / 4; ++k2) {                                  \
+            const int kk = (4 * k2 + lk) * BNR_GRAM_CS;                                                   \
+            double a0 = bufJ[kk + wj * 32 + li], a1 = bufJ[kk + wj * 32 + 16 + li];                       \
+            double b0 = bufI[kk + wi * 32 + li], b1 = bufI[kk + wi * 32 + 16 + li];                       \
+            c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);                             \
+            c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);                             \
+            c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);                             \
+            c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);                             \
+        }                                                                                                 \
+    } while (0)
+    // nbatch is even or odd; batches beyond the end read the zero-padded tail of X (q_pad has one spare batch per slice? no:
+    // the host pads q_pad so that loads up to batch nbatch+1 of the LAST K-group stay inside the allocation)
+    BNR_GRAM_LOAD(riA, rjA, svA, 0);
+    BNR_GRAM_STORE(riA, rjA, svA, 0);
+    BNR_GRAM_LOAD(riA, rjA, svA, 1);
+    BNR_GRAM_LOAD(riB, rjB, svB, 2);
+    __syncthreads();
+    BNR_GSTAMP(1);
+    int b = 0;
+    for (; b + 1 < nbatch; b += 2) {
+        BNR_GRAM_COMPUTE(0);
+        BNR_GRAM_STORE(riA, rjA, svA, 1);          // batch b+1
+        BNR_GRAM_LOAD(riA, rjA, svA, b + 3);
+        __syncthreads();
+        BNR_GRAM_COMPUTE(1);
+        BNR_GRAM_STORE(riB, rjB, svB, 0);          // batch b+2
+        BNR_GRAM_LOAD(riB, rjB, svB, b + 4);
+        __syncthreads();
     }
+    if (b < nbatch) { BNR_GRAM_COMPUTE(0); __syncthreads(); }
+    BNR_GSTAMP(2);
+    const int i0 = 0, j0 = 0;
+    (void)i0; (void)j0;
     // tile element (i,j) lives at [j*64 + i]; this lane: j = wj*32 + jt*16 + (lane>>4) + 4 r, i = wi*32 + it*16 + (lane&15)
     double *mine = sred + (size_t)kg * (BNR_GT * BNR_GT);
     const int jb = wj * 32 + (lane >> 4), ib = wi * 32 + (lane & 15);
@@ -433,6 +501,10 @@ __global__ __launch_bounds__(1024) void k_gram(bnr_dev cd, int s)
 #pragma unroll
     for (int idx = threadIdx.x; idx < BNR_GT * BNR_GT; idx += 1024)
         out[idx] = (sred[idx] + sred[BNR_GT * BNR_GT + idx]) + (sred[2 * BNR_GT * BNR_GT + idx] + sred[3 * BNR_GT * BNR_GT + idx]);
+    BNR_GSTAMP(3);
+#ifdef BNR_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 256) cd.dbg[768 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // E = extended matrix of the factorization, (2 n_pad + 32) x n_pad, column-major, leading dimension ldE:
@@ -750,6 +822,12 @@ __global__ __launch_bounds__(256) void k_backproj(bnr_dev cd, int s, int flags)
     const int e0 = blockIdx.x * cd.chunk_bp, ne = min(cd.chunk_bp, cd.q - e0);
     const size_t ld = cd.n_pad;
     const double tau2 = row[ROW_TAU2], tau = sqrt(tau2);
+#ifdef BNR_STAMPS
+#define BNR_BSTAMP(slot) do { if (tid == 0 && blockIdx.x == 7) cd.dbg[320 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BNR_BSTAMP(slot) do { } while (0)
+#endif
+    BNR_BSTAMP(0);
     if (flags & 1) {
         for (int i = tid; i < cd.n_pad; i += blockDim.x) sa[i] = cd.a4[i];
         __syncthreads();
@@ -765,6 +843,7 @@ __global__ __launch_bounds__(256) void k_backproj(bnr_dev cd, int s, int flags)
         }
     }
     __syncthreads();
+    BNR_BSTAMP(1);
     if (wave != 0) return;
     int cap = 0;
     const int e = e0 + lane;
@@ -785,6 +864,7 @@ __global__ __launch_bounds__(256) void k_backproj(bnr_dev cd, int s, int flags)
             row[cd.o_S + e] = Snew;
         } else Snew = row[cd.o_S + e];
     }
+    BNR_BSTAMP(2);
     if (!(flags & 4)) { if (cap) atomicAdd((unsigned long long *)&cd.counters[2], 1ull); return; }
     double *ps = cd.Psum + (size_t)blockIdx.x * (1 + 3 * R);
     double ssum = wave_sum(act ? Snew : 0.0);
@@ -803,38 +883,92 @@ __global__ __launch_bounds__(256) void k_backproj(bnr_dev cd, int s, int flags)
             if (lane == 0) ps[1 + 3 * r + c] = term;
         }
     }
+    BNR_BSTAMP(3);
     if (cap) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
 }
 
 // ===================================================================================== k_tail
-// One block of 1024 threads.  mask bits: 1 theta, 2 Delta, 4 M, 8 mu, 16 Lambda, 32 pi, 64 carried sums (res, rr,
-// sig_q for the next tau2), 128 ring wrap copy, 256 inv(M)/logdet M for the next k_node, 512 pre-draw the next tau2.
+// One block of 1024 threads.  mask bits: 1 theta, 2 Delta, 4 M, 8 mu, 16 Lambda, 32 pi, 64 carried sums (rr, sig_q for
+// the next tau2), 128 ring wrap copy, 256 inv(M)/logdet M for the next k_node, 512 pre-draw the next tau2.
 // When a bit is clear the value already in `row` is kept.
 // xg_src: 0 = cd.xg (from k_solve_gemv); 1 = sum of the PG partials (X*gamma by k_xpass bit2).
-// Independent scalar draws are placed on different wavefronts so that their (long, scalar) sampler code runs concurrently.
+// Independent scalar draws sit on different wavefronts so that their long scalar sampler code runs concurrently; the
+// small R x R matrix work runs on single wavefronts with wave-level synchronisation only (no block barriers).
+__device__ __forceinline__ void bnr_wsync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
+// in-place lower Cholesky of an LDS matrix by ONE wavefront (all 64 lanes call); returns 0 ok / 1 not positive definite
+__device__ inline int wave_chol(double *A, int R, int lane)
+{
+    for (int j = 0; j < R; ++j) {
+        bnr_wsync();
+        double d = A[j + R * j];
+        if (!(d > 0.0) || !isfinite(d)) return 1;
+        d = sqrt(d);
+        bnr_wsync();
+        for (int i = j + lane; i < R; i += 64) A[i + R * j] = (i == j) ? d : A[i + R * j] / d;
+        bnr_wsync();
+        int m = R - j - 1;
+        for (int idx = lane; idx < m * m; idx += 64) {
+            int c = j + 1 + idx / m, i = j + 1 + idx % m;
+            if (i >= c) A[i + R * c] = A[i + R * c] - A[i + R * j] * A[c + R * j];
+        }
+    }
+    bnr_wsync();
+    return 0;
+}
+// T = inverse of the lower-triangular LDS matrix A (column j by lane j; R <= 32)
+__device__ inline void wave_tri_inverse(const double *A, double *T, int R, int lane)
+{
+    if (lane < R) {
+        const int j = lane;
+        for (int i = 0; i < R; ++i) {
+            double v = 0.0;
+            if (i == j) v = 1.0 / A[j + R * j];
+            else if (i > j) {
+                double sacc = 0.0;
+                for (int k = j; k < i; ++k) sacc += A[i + R * k] * T[k + R * j];
+                v = -sacc / A[i + R * i];
+            }
+            T[i + R * j] = v;
+        }
+    }
+    bnr_wsync();
+}
+
 __global__ __launch_bounds__(1024) void k_tail(bnr_dev cd, int s, int mask, int xg_src)
 {
-    __shared__ double sred[32];
+    extern __shared__ double su[];               // R x V: u of this row (staged once, used by Psi and by the q pass)
+    __shared__ double sred[3 * 16];
     __shared__ double sPsi[BNR_RMAX * BNR_RMAX], sA[BNR_RMAX * BNR_RMAX], sT[BNR_RMAX * BNR_RMAX], sBm[BNR_RMAX * BNR_RMAX];
     __shared__ double sll[3 * BNR_RMAX + 1], slam[BNR_RMAX], spi[3 * BNR_RMAX];
     __shared__ double sval[8];
+    __shared__ int sflag[2];
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     if (P.wrap & 2) return;                      // placeholder entry in front of the first sweep of a run
     double *row = cd.trace + (size_t)P.row * cd.rowlen;
     const double *prev = cd.trace + (size_t)P.prev * cd.rowlen;
-    const int R = cd.R, V = cd.V, q = cd.q, n = cd.n, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int R = cd.R, V = cd.V, q = cd.q, n = cd.n, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
     const double tau2 = row[ROW_TAU2];
     int cap = 0;
+#ifdef BNR_STAMPS
+#define BNR_TSTAMP(slot) do { if (tid == 0) cd.dbg[256 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BNR_TSTAMP(slot) do { } while (0)
+#endif
+    BNR_TSTAMP(0);
     if (tid < R) slam[tid] = row[cd.o_lam + tid];
-    if (tid == 0) { sval[1] = row[ROW_MU]; sval[2] = 0.0; sval[3] = 0.0; }
+    if (tid == 0) { sval[1] = row[ROW_MU]; sflag[0] = 0; sflag[1] = 0; }
+    for (int i = tid; i < R * V; i += blockDim.x) su[i] = row[cd.o_u + i];
 
-    // ---- phase 1: reductions.  Psum partials (32 lanes per output, fixed order); sum xi / #nonzero; sum(y - X gamma)
+    // ---- phase 1: reductions.  Psum partials (32 lanes per output, fixed order); X gamma from the PG partials
     if (mask & (1 | 16)) {
         const int nout = 1 + 3 * R, j = tid >> 5, t = tid & 31;
         for (int jj = j; jj < nout; jj += 32) {
-            double a = 0.0;
-            for (int b = t; b < cd.nblk_bp; b += 32) a += cd.Psum[(size_t)b * nout + jj];
-            a = half_wave_sum(a);
+            double a0 = 0.0, a1 = 0.0;
+            int b = t;
+            for (; b + 32 < cd.nblk_bp; b += 64) { a0 += cd.Psum[(size_t)b * nout + jj]; a1 += cd.Psum[(size_t)(b + 32) * nout + jj]; }
+            if (b < cd.nblk_bp) a0 += cd.Psum[(size_t)b * nout + jj];
+            double a = half_wave_sum(a0 + a1);
             if (t == 0) sll[jj] = a;             // sll[0] = sum S, sll[1 + 3r + c] = log-likelihood sums
         }
     }
@@ -851,31 +985,33 @@ __global__ __launch_bounds__(1024) void k_tail(bnr_dev cd, int s, int mask, int 
         }
     }
     __syncthreads();
+    BNR_TSTAMP(1);
+    // sum xi, #nonzero xi, sum (y - X gamma): one three-way block reduction
     double sxi = 0.0, snz = 0.0, sres = 0.0;
-    if (mask & (2 | 4)) {
-        for (int v = tid; v < V; v += blockDim.x) { double x = row[cd.o_xi + v]; sxi += x; snz += (!(fabs(x) <= 0.1)) ? 1.0 : 0.0; }
-        sxi = block_sum(sxi, sred);
-        snz = block_sum(snz, sred);
-    }
-    if (mask & 8) {
-        for (int i = tid; i < n; i += blockDim.x) sres += cd.y[i] - cd.xg[i];
-        sres = block_sum(sres, sred);
+    if (mask & (2 | 4)) for (int v = tid; v < V; v += blockDim.x) { double x = row[cd.o_xi + v]; sxi += x; snz += (!(fabs(x) <= 0.1)) ? 1.0 : 0.0; }
+    if (mask & 8) for (int i = tid; i < n; i += blockDim.x) sres += cd.y[i] - cd.xg[i];
+    if (mask & (2 | 4 | 8)) {
+        sxi = wave_sum(sxi); snz = wave_sum(snz); sres = wave_sum(sres);
+        if (lane == 0) { sred[wave] = sxi; sred[16 + wave] = snz; sred[32 + wave] = sres; }
     }
     // ---- phase 2: Psi = I + sum_v u_v u_v' (gibbs.jl:516-525), sequential over v per entry (the reference's order)
-    const double df = cd.nu + snz;
     if (mask & 4) {
-        const double *un = row + cd.o_u;
         for (int idx = tid; idx < R * R; idx += blockDim.x) {
             int a = idx % R, b = idx / R;
             double sacc = (a == b) ? 1.0 : 0.0;
-#pragma unroll 4
-            for (int v = 0; v < V; ++v) sacc += un[a + R * v] * un[b + R * v];
+            for (int v = 0; v < V; ++v) sacc += su[a + R * v] * su[b + R * v];
             sPsi[idx] = sacc;
             sA[idx] = sacc;
         }
     }
     __syncthreads();
-    // ---- phase 3: independent scalar draws on separate wavefronts
+    if (mask & (2 | 4 | 8)) {
+        sxi = 0.0; snz = 0.0; sres = 0.0;
+        for (int w = 0; w < nw; ++w) { sxi += sred[w]; snz += sred[16 + w]; sres += sred[32 + w]; }
+    }
+    const double df = cd.nu + snz;
+    BNR_TSTAMP(2);
+    // ---- phase 3: independent work on separate wavefronts
     if (wave == 0 && lane == 0 && (mask & 1)) {                                  // theta (gibbs.jl:476-479)
         double g = bnr_gamma(cd.seed, cd.zeta + (V * (V + 1)) / 2.0, P.it, SITE_THETA, 0, &cap);
         row[ROW_THETA] = g * (2.0 / (2.0 * cd.iota + sll[0]));
@@ -909,8 +1045,9 @@ __global__ __launch_bounds__(1024) void k_tail(bnr_dev cd, int s, int mask, int 
             double lv = bnr_lambda_value(bnr_categorical3(w0, w1, w2, ua));
             row[cd.o_lam + r] = lv; slam[r] = lv;
         }
+        bnr_wsync();
         if (mask & 32) {
-            for (int t0 = 0; t0 < 3 * R; t0 += 64) {                             // wave-synchronous: slam written above by this wave
+            for (int t0 = 0; t0 < 3 * R; t0 += 64) {
                 int t = t0 + lane;
                 if (t < 3 * R) {
                     int r = t / 3, c = t % 3;
@@ -925,105 +1062,93 @@ __global__ __launch_bounds__(1024) void k_tail(bnr_dev cd, int s, int mask, int 
             }
         }
     }
-    if (wave >= 4 && (mask & 4)) {                                               // Bartlett factor entries (gibbs.jl:545)
-        for (int idx = tid - 256; idx < R * R; idx += blockDim.x - 256) {
+    if (wave == 4 && (mask & 4)) {                                               // Bartlett diagonal: chi-square draws
+        for (int j = lane; j < R; j += 64) sBm[j + R * j] = sqrt(2.0 * bnr_gamma(cd.seed, 0.5 * (df - j), P.it, SITE_M_CHI, (uint32_t)j, &cap));
+    }
+    if (wave == 5 && (mask & 4)) {                                               // Bartlett strictly lower: normals; upper: 0
+        for (int idx = lane; idx < R * R; idx += 64) {
             int i = idx % R, j = idx / R;
-            double v = 0.0;
-            if (i == j) v = sqrt(2.0 * bnr_gamma(cd.seed, 0.5 * (df - j), P.it, SITE_M_CHI, (uint32_t)j, &cap));
-            else if (i > j) v = bnr_normal(cd.seed, P.it, SITE_M_N, (uint32_t)(i * R + j), 0);
-            sBm[idx] = v;
+            if (i > j) sBm[idx] = bnr_normal(cd.seed, P.it, SITE_M_N, (uint32_t)(i * R + j), 0);
+            else if (i < j) sBm[idx] = 0.0;
         }
     }
+    if (wave == 6 && (mask & 4)) {                                               // C = chol(Psi), retry ladder gibbs.jl:529-543
+        int f = wave_chol(sA, R, lane);
+        if (f) {
+            if (lane == 0) atomicAdd((unsigned long long *)&cd.counters[0], 1ull);
+            for (int idx = lane; idx < R * R; idx += 64) sA[idx] = sPsi[idx] + ((idx % R == idx / R) ? 1e-5 : 0.0);
+            f = wave_chol(sA, R, lane);
+            if (f && lane == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[5], 1ull); }
+        }
+        for (int idx = lane; idx < R * R; idx += 64) { int a = idx % R, b = idx / R; if (a < b) sA[idx] = 0.0; }
+    }
     __syncthreads();
+    BNR_TSTAMP(3);
     if ((mask & 32) && tid < 3 * R) {
         int r = tid / 3, c = tid % 3;
         row[cd.o_pi + r + R * c] = spi[tid] / (spi[3 * r] + spi[3 * r + 1] + spi[3 * r + 2]);
     }
-    // ---- phase 4: M ~ InverseWishart(df, Psi) = (C A^-T)(C A^-T)', C = chol(Psi), A = Bartlett factor
-    if (mask & 4) {
-        int f = lds_chol(sA, R, tid);
-        if (f) {                                                                  // retry ladder :529-543
-            if (tid == 0) atomicAdd((unsigned long long *)&cd.counters[0], 1ull);
-            __syncthreads();
-            for (int i = tid; i < R; i += blockDim.x) sPsi[i + R * i] += 1e-5;
-            __syncthreads();
-            for (int idx = tid; idx < R * R; idx += blockDim.x) sA[idx] = sPsi[idx];
-            __syncthreads();
-            f = lds_chol(sA, R, tid);
-            if (f && tid == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[5], 1ull); }
-        }
-        for (int idx = tid; idx < R * R; idx += blockDim.x) { int a = idx % R, b = idx / R; if (a < b) sA[idx] = 0.0; }
-        // T = A^-1 (lower): column j by thread j
-        if (tid < R) {
-            int j = tid;
-            for (int i = 0; i < R; ++i) {
-                double v = 0.0;
-                if (i == j) v = 1.0 / sBm[j + R * j];
-                else if (i > j) {
-                    double sacc = 0.0;
-                    for (int k = j; k < i; ++k) sacc += sBm[i + R * k] * sT[k + R * j];
-                    v = -sacc / sBm[i + R * i];
-                }
-                sT[i + R * j] = v;
+    // ---- phase 4 (wavefront 0 only, wave-level sync): M ~ InverseWishart(df, Psi) = (C A^-T)(C A^-T)', then inv(M), logdet M
+    if (wave == 0 && (mask & (4 | 256))) {
+        if (mask & 4) {
+            wave_tri_inverse(sBm, sT, R, lane);                                   // T = A^-1
+            for (int idx = lane; idx < R * R; idx += 64) {                        // B = C T' -> sPsi
+                int a = idx % R, b = idx / R;
+                double sacc = 0.0;
+                for (int k = 0; k < R; ++k) sacc += sA[a + R * k] * sT[b + R * k];
+                sPsi[idx] = sacc;
             }
-        }
-        __syncthreads();
-        for (int idx = tid; idx < R * R; idx += blockDim.x) {                     // B = C T' -> sPsi
-            int a = idx % R, b = idx / R;
-            double sacc = 0.0;
-            for (int k = 0; k < R; ++k) sacc += sA[a + R * k] * sT[b + R * k];
-            sPsi[idx] = sacc;
-        }
-        __syncthreads();
-        for (int idx = tid; idx < R * R; idx += blockDim.x) {                     // M = B B'
-            int a = idx % R, b = idx / R;
-            double sacc = 0.0;
-            for (int k = 0; k < R; ++k) sacc += sPsi[a + R * k] * sPsi[b + R * k];
-            row[cd.o_M + idx] = sacc;
-            sBm[idx] = sacc;
-        }
-        __syncthreads();
-    } else if (mask & 256) {
-        for (int idx = tid; idx < R * R; idx += blockDim.x) sBm[idx] = row[cd.o_M + idx];
-        __syncthreads();
-    }
-    // ---- phase 5: inv(M) and logdet M for the next update_u_xi! (gibbs.jl:315), by Cholesky of M
-    if (mask & 256) {
-        for (int idx = tid; idx < R * R; idx += blockDim.x) sA[idx] = sBm[idx];
-        __syncthreads();
-        int f = lds_chol(sA, R, tid);
-        if (f && tid == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[6], 1ull); }
-        if (wave == 0) {
-            double ld = 0.0;
-            for (int i = 0; i < R; ++i) ld += 2.0 * log(sA[i + R * i]);
-            for (int j = 0; j < R; ++j) {
-                double b = (lane == j) ? 1.0 : 0.0;
-                b = wave_fwd_solve(sA, R, lane, b);
-                b = wave_bwd_solve_T(sA, R, lane, b);
-                if (lane < R) cd.Minv[lane + R * j] = b;
+            bnr_wsync();
+            for (int idx = lane; idx < R * R; idx += 64) {                        // M = B B'
+                int a = idx % R, b = idx / R;
+                double sacc = 0.0;
+                for (int k = 0; k < R; ++k) sacc += sPsi[a + R * k] * sPsi[b + R * k];
+                row[cd.o_M + idx] = sacc;
+                sBm[idx] = sacc;
             }
-            if (lane == 0) cd.Minv[R * R] = ld;
+        } else {
+            for (int idx = lane; idx < R * R; idx += 64) sBm[idx] = row[cd.o_M + idx];
+        }
+        bnr_wsync();
+        if (mask & 256) {
+            // inv(M) = Lm^-T Lm^-1 with Lm = chol(M) (gibbs.jl:315 computes inv(M); same matrix, triangular-inverse route)
+            for (int idx = lane; idx < R * R; idx += 64) sA[idx] = sBm[idx];
+            int f = wave_chol(sA, R, lane);
+            if (f && lane == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[6], 1ull); }
+            double ldm = 0.0;
+            for (int i = 0; i < R; ++i) ldm += 2.0 * log(sA[i + R * i]);
+            wave_tri_inverse(sA, sT, R, lane);                                    // Linv (lower)
+            for (int idx = lane; idx < R * R; idx += 64) {
+                int a = idx % R, b = idx / R, k0 = a > b ? a : b;
+                double sacc = 0.0;
+                for (int k = k0; k < R; ++k) sacc += sT[k + R * a] * sT[k + R * b];
+                cd.Minv[idx] = sacc;
+            }
+            if (lane == 0) cd.Minv[R * R] = ldm;
         }
     }
-    // ---- phase 6: carried sums for the next update_tau2! (gibbs.jl:270-273): res = y - mu - X gamma, rr = res'res,
+    BNR_TSTAMP(4);
+    // ---- phase 6: carried sums for the next update_tau2! (gibbs.jl:270-273): rr = |y - mu - X gamma|^2,
     //      sig_q = sum_e ((gamma_e - W(u,lam)_e)^2 / 2) / S_e  with the NEW lambda; optionally pre-draw the next tau2
     if (mask & 64) {
-        __syncthreads();
         const double mu = sval[1];
-        double racc = 0.0;
-        for (int i = tid; i < cd.n_pad; i += blockDim.x) {
-            double rv = (i < n) ? (cd.y[i] - mu - cd.xg[i]) : 0.0;
-            racc += rv * rv;
+        double racc = 0.0, qacc = 0.0;
+        if (wave != 0) {                          // wavefront 0 is busy with the matrix work above
+            const int t = tid - 64, nt = blockDim.x - 64;
+            for (int i = t; i < n; i += nt) { double rv = cd.y[i] - mu - cd.xg[i]; racc += rv * rv; }
+            for (int e = t; e < q; e += nt) {
+                double g = row[cd.o_gamma + e] - edge_W(su, slam, R, cd.el[e], cd.ek[e]);
+                qacc += ((g * g) / 2.0) / row[cd.o_S + e];
+            }
         }
-        racc = block_sum(racc, sred);
-        double qacc = 0.0;
-        const double *un = row + cd.o_u;
-        for (int e = tid; e < q; e += blockDim.x) {
-            double g = row[cd.o_gamma + e] - edge_W(un, slam, R, cd.el[e], cd.ek[e]);
-            qacc += ((g * g) / 2.0) / row[cd.o_S + e];
-        }
-        qacc = block_sum(qacc, sred);
+        racc = wave_sum(racc); qacc = wave_sum(qacc);
+        __syncthreads();
+        if (lane == 0) { sred[wave] = racc; sred[16 + wave] = qacc; }
+        __syncthreads();
+        BNR_TSTAMP(5);
         if (tid == 0) {
+            racc = 0.0; qacc = 0.0;
+            for (int w = 0; w < nw; ++w) { racc += sred[w]; qacc += sred[16 + w]; }
             cd.scal[SC_RR] = racc; cd.scal[SC_SIGQ] = qacc;
             if (mask & 512) {
                 double sigma = racc / 2.0 + qacc;
@@ -1039,11 +1164,13 @@ __global__ __launch_bounds__(1024) void k_tail(bnr_dev cd, int s, int mask, int 
         double *dst = cd.trace;
         for (int i = tid; i < cd.rowlen; i += blockDim.x) dst[i] = row[i];
     }
+    BNR_TSTAMP(6);
     if (cap) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
 }
 
 // advances the plan base after a batch of sweeps (last node of the captured graph)
 __global__ void k_advance(int *pbase, int by) { if (threadIdx.x == 0 && blockIdx.x == 0) pbase[0] += by; }
+__global__ void k_stamp(unsigned long long *dbg, int slot) { if (threadIdx.x == 0) dbg[slot] = __builtin_amdgcn_s_memrealtime(); }
 __global__ void k_setbase(int *pbase, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) pbase[0] = v; }
 
 // ===================================================================================== k_init_prior

@@ -133,6 +133,8 @@ int bnr_chain_last_timing(bnr_chain *chain, int32_t which, double *avg_us, int64
 
 /* diagnostics: in-kernel cycle stamps of a -DBNR_STAMPS build (zeros otherwise) */
 int bnr_chain_debug_read(bnr_chain *chain, uint64_t *out, int32_t count);
+/* diagnostics: average duration of `reps` back-to-back launches of the Gram kernel on the chain's stream */
+int bnr_chain_debug_time_gram(bnr_chain *chain, int32_t reps, double *avg_us);
 /* diagnostics: copy an internal work buffer to the host (0 = factorization matrix E, 1 = rhs b, 2 = a4, 3 = Gram partials) */
 int bnr_chain_debug_copy(bnr_chain *chain, int32_t which, double *out, int64_t count);
 

@@ -10,6 +10,10 @@ print("chol_step block 0 (role A, diagonal panel): shader cycles per phase [load
 for p in range(16):
     t = d[p]
     print(p, "update", int(t[2]-t[0]), "sweep", int(t[3]-t[2]), "store", int(t[4]-t[3]), "total", int(t[4]-t[0]))
+d = ch.debug_read(300)[256:264].astype(np.int64)
+print("k_tail (thread 0) cycles: load+reduce %d, sums+Psi %d, draws %d, M/Minv(wave0) %d, qpass %d, final %d, total %d" % (d[1]-d[0], d[2]-d[1], d[3]-d[2], d[4]-d[3], d[5]-d[4], d[6]-d[5], d[6]-d[0]))
+d = ch.debug_read(330)[320:324].astype(np.int64)
+print("k_backproj block 7 cycles: dots %d, gamma+GIG %d, sums %d, total %d" % (d[1]-d[0], d[2]-d[1], d[3]-d[2], d[3]-d[0]))
 from oracle import bnr_oracle as bo
 o = bo.Oracle(X, y, 7, 6, 20240501, chain=1, pdf_mode=1); o.init_prior(); o.run(2, 6, 6)
 g = ch.fetch(1, 6)
