@@ -216,6 +216,7 @@ int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const dou
     TRY(dev_alloc(c, &d.res, d.n_pad));
     TRY(dev_alloc(c, &d.xg, d.n_pad));
     TRY(dev_alloc(c, &d.bw, d.n_pad));
+    TRY(dev_alloc(c, &d.wv, d.n_pad));
     TRY(dev_alloc(c, &d.scal, 16));
     TRY(dev_alloc(c, &d.Minv, BNR_RMAX * BNR_RMAX + 1));
     TRY(dev_alloc(c, &d.Psum, (size_t)d.nblk_bp * (1 + 3 * R)));
@@ -307,15 +308,17 @@ static void launch_gram(bnr_chain *c, int s, hipStream_t st, bool timed)
     hipLaunchKernelGGL(k_gram_reduce, dim3(ntl, 4), dim3(256), 0, st, c->d, s);
 }
 static void launch_rhs(bnr_chain *c, int s) { hipLaunchKernelGGL(k_rhs, dim3(c->d.n_pad / 64), dim3(256), 0, c->stream, c->d, s); }
-static void launch_chol(bnr_chain *c, int s)
+static void launch_chol(bnr_chain *c, int s, hipStream_t st)
 {
     const int nbk = c->d.n_pad / BNR_NB;
-    hipLaunchKernelGGL(k_rhs_place, dim3((c->d.n_pad + 255) / 256), dim3(256), 0, c->stream, c->d);
     for (int p = 0; p < nbk; ++p)
-        hipLaunchKernelGGL(k_chol_step, dim3(bnr_chol_npanel(nbk, p) + bnr_chol_ntile(nbk, p)), dim3(256), 0, c->stream, c->d, p, s);
+        hipLaunchKernelGGL(k_chol_step, dim3(bnr_chol_npanel(nbk, p) + bnr_chol_ntile(nbk, p)), dim3(256), 0, st, c->d, p, s);
 }
 static void launch_solve(bnr_chain *c)
-{ hipLaunchKernelGGL(k_solve_gemv, dim3(c->d.n_pad / BNR_NB), dim3(256), (c->d.n_pad + 256) * sizeof(double), c->stream, c->d); }
+{
+    hipLaunchKernelGGL(k_solve_w, dim3(c->d.n_pad / 4), dim3(256), 0, c->stream, c->d);
+    hipLaunchKernelGGL(k_solve_a4, dim3(c->d.n_pad / BNR_NB), dim3(1024), (c->d.n_pad + 32 * 33) * sizeof(double), c->stream, c->d);
+}
 static void launch_backproj(bnr_chain *c, int s, int flags)
 { hipLaunchKernelGGL(k_backproj, dim3(c->d.nblk_bp), dim3(256), (c->d.n_pad + 64) * sizeof(double), c->stream, c->d, s, flags); }
 static void launch_tail(bnr_chain *c, int s, int mask, int xg_src)
@@ -330,33 +333,32 @@ static hipEvent_t next_event(bnr_chain *c)
 // mu, Lambda, pi and the carried sums) is issued at the head of this one, because together with update_tau2!/update_u_xi!
 // and the X W pass it is independent of the Gram matrix X diag(S) X' of this sweep: the two branches run concurrently
 // (fork/join on two streams, also inside the captured graph) and meet before the factorization.
-//   branch A (stream):  tail(s-1) -> k_node(s) -> k_xpass(s) -> k_rhs(s)
-//   branch B (stream2): k_gram(s) -> k_gram_reduce
-//   joined:             k_chol_step x nbk -> k_solve_gemv -> k_backproj(s)
+//   branch A (stream):  tail(s-1) -> k_node(s) -> k_xpass(s) -> k_rhs(s)                 (~100 us of scalar/latency work)
+//   branch B (stream2): k_gram(s) -> k_gram_reduce -> k_chol_step x nbk                  (the factorization needs no rhs)
+//   joined:             k_solve_w -> k_solve_a4 -> k_backproj(s)
 static void launch_sweep(bnr_chain *c, int s, bool prev_tail)
 {
     const bool timed = c->profiling != 0;
     const bool overlap = c->overlap != 0;
+    hipStream_t sb = overlap ? c->stream2 : c->stream;
     if (overlap) {
-        hipEvent_t ef = next_event(c), ej = next_event(c);
+        hipEvent_t ef = next_event(c);
         hipEventRecord(ef, c->stream);
         hipStreamWaitEvent(c->stream2, ef, 0);
-        launch_gram(c, s, c->stream2, timed);
-        hipEventRecord(ej, c->stream2);
+        launch_gram(c, s, sb, timed);
+        launch_chol(c, s, sb);
+        hipEventRecord(next_event(c), c->stream2);
     }
     if (prev_tail) launch_tail(c, s - 1, 1023, 0);
     launch_node(c, s, 3);
     launch_xpass(c, s, 3);
     launch_rhs(c, s);
     if (overlap) hipStreamWaitEvent(c->stream, c->fj[c->fj_next - 1], 0);
-    else launch_gram(c, s, c->stream, timed);
-    launch_chol(c, s);
+    else { launch_gram(c, s, sb, timed); launch_chol(c, s, sb); }
     launch_solve(c);
     launch_backproj(c, s, 7);
 }
 
-// Enqueue `count` consecutive sweeps starting at the current plan base.  Full batches of graph_k sweeps replay one
-// captured hipGraph (kernel boundaries without host launch cost); the remainder is launched eagerly.
 // with profiling on: after a batch, read the HIP events recorded around the k_gram launches of that batch (recorded on
 // the stream the kernel runs on)
 static int collect_gram_times(bnr_chain *c, int nsweeps)
@@ -604,7 +606,7 @@ int bnr_update_gamma(bnr_chain *c, int32_t row, int64_t iter)
     launch_xpass(c, 0, 3);
     launch_gram(c, 0, c->stream, false);
     launch_rhs(c, 0);
-    launch_chol(c, 0);
+    launch_chol(c, 0, c->stream);
     launch_solve(c);
     launch_backproj(c, 0, 1);
     return hook_end(c, "update_gamma");

@@ -48,7 +48,7 @@ struct bnr_dev {
     double *Gpart, *E;           // Gram partial tiles; E = extended matrix of the factorization (see k_gram_reduce)
     int ksplit, ntile;           // ntile = n_pad/64
     const int *gmap;             // k_gram: workgroup id -> (tile | ks << 16), XCD-aware (K slice x on the workgroups of XCD label x)
-    double *a3, *xw, *a4, *res, *xg, *bw;   // n_pad each (bw: right-hand side b = a1 - a3)
+    double *a3, *xw, *a4, *res, *xg, *bw, *wv;   // n_pad each (bw: right-hand side b = a1 - a3; wv: w = L^-1 b)
     double *scal;                // [0]=rr (sum res^2), [1]=sig_q (sum (g^2/2)/S), [2]=tau (sqrt tau2 of current row), [3..4] pre-drawn tau2
     double *Minv;                // R*R + 1: inv(M) and logdet M of the state the next k_node reads (written by k_tail)
     double *Psum;                // nblk_bp x (1+3R) partial sums from k_backproj
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(1024) void k_gram(bnr_dev cd, int s)
 // E = extended matrix of the factorization, (2 n_pad + 32) x n_pad, column-major, leading dimension ldE:
 //     rows [0, n_pad)            G + I  (lower triangle)                      -> L
 //     rows [n_pad, 2 n_pad)      Y = I                                        -> L^-T   (back substitution becomes a GEMV)
-//     rows [2 n_pad, 2 n_pad+32) row 0 = b' (right-hand side), rest 0         -> w' = (L^-1 b)'  (forward substitution for free)
+//     rows [2 n_pad, 2 n_pad+32) unused padding
 // k_gram_reduce: G = sum_ks partial + I into the lower tiles of E, and Y = I.  grid = (lower tiles, 4), 256 threads.
 __host__ __device__ inline int bnr_ldE(int n_pad) { return 2 * n_pad + BNR_NB; }
 
@@ -570,12 +570,12 @@ __device__ __forceinline__ double bnr_rsqrt(double x)
 }
 
 #define BNR_LP (BNR_NB + 1)
-__host__ __device__ inline int bnr_chol_npanel(int nbk, int p) { (void)p; return nbk + 2; }
+__host__ __device__ inline int bnr_chol_npanel(int nbk, int p) { (void)p; return nbk + 1; }
 __host__ __device__ inline int bnr_chol_ntile(int nbk, int p)
 {
     if (p == 0) return 0;
     int m = nbk - (p + 1);
-    return m * (m + 1) / 2 + m * (p + 1);        // matrix tiles + (p identity block rows + the b block) per column
+    return m * (m + 1) / 2 + m * p;              // matrix tiles + p identity block rows per column
 }
 
 // 16x16 tile of  C - A B'  over K = 32:  C[m][n], m <-> column, n <-> row (n = lane & 15 is contiguous in memory).
@@ -618,9 +618,8 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(bnr_dev cd, int p, int s)
             rho = p + 1 + ti; j = p + 1 + tj;
         } else {
             t -= ntri;
-            j = p + 1 + t / (p + 1);
-            int rr = t % (p + 1);
-            rho = (rr < p) ? nbk + rr : 2 * nbk;           // identity block row rr, or the b block
+            j = p + 1 + t / p;
+            rho = nbk + t % p;                             // identity block row
         }
         double *cp = E + (size_t)(rho * BNR_NB + nt * 16 + ln) + ld * (size_t)(j * BNR_NB + mt * 16 + lq);
         bnr_d4 c;
@@ -648,8 +647,7 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(bnr_dev cd, int p, int s)
     BNR_STAMP(0);
     int rho;                                               // own block row
     if (b < nbk - p) rho = p + b;                          // matrix rows p..nbk-1
-    else if (b < nbk + 1) rho = nbk + (b - (nbk - p));     // identity block rows 0..p
-    else rho = 2 * nbk;                                    // the b block
+    else rho = nbk + (b - (nbk - p));                      // identity block rows 0..p
     {
         const double *dp = E + (size_t)(pc + nt * 16 + ln) + ld * (size_t)(pc + mt * 16 + lq);
         const double *bp = E + (size_t)(rho * BNR_NB + nt * 16 + ln) + ld * (size_t)(pc + mt * 16 + lq);
@@ -762,41 +760,45 @@ __global__ __launch_bounds__(256) void k_rhs(bnr_dev cd, int s)
         cd.bw[i] = bb;                         // b, kept for the bookkeeping after the solve
     }
 }
-// scatters b' into the b block of E (after k_gram_reduce of the same sweep: E is rewritten there).  grid = n_pad/256.
-__global__ __launch_bounds__(256) void k_rhs_place(bnr_dev cd)
+// Solve with Y = L^-T (rows [n_pad, 2 n_pad) of E, upper triangular, column-major): a4 = Y (Y' b).
+// The factorization itself never sees b, so the scalar branch of the sweep (tail, node, X W pass, k_rhs) only has to be
+// finished here, not before the Cholesky.
+// k_solve_w: w_c = sum_{r <= c} Y[r,c] b_r  -- one wavefront per column c (contiguous).  grid = n_pad/4 blocks of 256.
+__global__ __launch_bounds__(256) void k_solve_w(bnr_dev cd)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x, np = cd.n_pad;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, np = cd.n_pad;
+    const int c = blockIdx.x * 4 + wave;
     const size_t ld = bnr_ldE(np);
-    if (c < np) {
-        cd.E[(size_t)(2 * np) + ld * c] = cd.bw[c];
-        for (int r = 1; r < BNR_NB; ++r) cd.E[(size_t)(2 * np + r) + ld * c] = 0.0;
-    }
+    const double *col = cd.E + (size_t)np + ld * (size_t)c;
+    const int rend = (c / BNR_NB + 1) * BNR_NB;            // entries below the diagonal block are exactly zero
+    double acc = 0.0;
+    for (int r = lane; r < rend; r += 64) acc = fma(col[r], cd.bw[r], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) cd.wv[c] = acc;
 }
-
-// a4 = L^-T w = Y w : a4_r = sum_{c >= block(r)} Y[r,c] w_c, then
-//   X gamma_new = X W + tau X sz + tau G a4,  G a4 = b - a4   (no third pass over X).
-// grid = nbk blocks (one per block row of Y), 256 threads = 32 rows x 8 column groups.
-__global__ __launch_bounds__(256) void k_solve_gemv(bnr_dev cd)
+// k_solve_a4: a4_r = sum_{c >= block(r)} Y[r,c] w_c, then X gamma_new = X W + tau X sz + tau G a4, G a4 = b - a4
+// (no third pass over X).  grid = nbk blocks (one per block row), 1024 threads = 32 rows x 32 column groups.
+__global__ __launch_bounds__(1024) void k_solve_a4(bnr_dev cd)
 {
-    extern __shared__ double shs[];                         // n_pad (w) + 8*32 partials
+    extern __shared__ double shs[];                         // n_pad (w) + 32*33 partials
     double *swv = shs, *spart = shs + cd.n_pad;
     const int np = cd.n_pad, tid = threadIdx.x;
     const size_t ld = bnr_ldE(np);
     const int rb = blockIdx.x, rl = tid & 31, cg = tid >> 5;
     const int cstart = rb * BNR_NB;
-    for (int c = cstart + tid; c < np; c += 256) swv[c] = cd.E[(size_t)(2 * np) + ld * c];
+    for (int c = cstart + tid; c < np; c += 1024) swv[c] = cd.wv[c];
     __syncthreads();
     const double *yrow = cd.E + (size_t)(np + rb * BNR_NB + rl);
     double acc0 = 0.0, acc1 = 0.0;
     int c = cstart + cg;
-    for (; c + 8 < np; c += 16) { acc0 = fma(yrow[ld * (size_t)c], swv[c], acc0); acc1 = fma(yrow[ld * (size_t)(c + 8)], swv[c + 8], acc1); }
-    for (; c < np; c += 8) acc0 = fma(yrow[ld * (size_t)c], swv[c], acc0);
-    spart[cg * 32 + rl] = acc0 + acc1;
+    for (; c + 32 < np; c += 64) { acc0 = fma(yrow[ld * (size_t)c], swv[c], acc0); acc1 = fma(yrow[ld * (size_t)(c + 32)], swv[c + 32], acc1); }
+    if (c < np) acc0 = fma(yrow[ld * (size_t)c], swv[c], acc0);
+    spart[cg * 33 + rl] = acc0 + acc1;
     __syncthreads();
     if (tid < 32) {
         double a4 = 0.0;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) a4 += spart[g * 32 + tid];
+        for (int g = 0; g < 32; ++g) a4 += spart[g * 33 + tid];
         const int r = rb * BNR_NB + tid;
         const double tau = cd.scal[SC_TAU], bb = cd.bw[r];
         cd.a4[r] = a4;
