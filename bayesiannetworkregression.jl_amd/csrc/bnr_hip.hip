@@ -320,7 +320,10 @@ static void launch_solve(bnr_chain *c)
     hipLaunchKernelGGL(k_solve_a4, dim3(c->d.n_pad / BNR_NB), dim3(1024), (c->d.n_pad + 32 * 33) * sizeof(double), c->stream, c->d);
 }
 static void launch_backproj(bnr_chain *c, int s, int flags)
-{ hipLaunchKernelGGL(k_backproj, dim3(c->d.nblk_bp), dim3(256), (c->d.n_pad + 64) * sizeof(double), c->stream, c->d, s, flags); }
+{
+    size_t lds = std::max<size_t>(c->d.n_pad + 64, (size_t)(3 * c->d.R + 1) * 33) * sizeof(double);
+    hipLaunchKernelGGL(k_backproj, dim3(c->d.nblk_bp), dim3(256), lds, c->stream, c->d, s, flags);
+}
 static void launch_tail(bnr_chain *c, int s, int mask, int xg_src)
 { hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), (size_t)c->d.R * c->d.V * sizeof(double), c->stream, c->d, s, mask, xg_src); }
 static hipEvent_t next_event(bnr_chain *c)

@@ -87,6 +87,8 @@ __device__ __forceinline__ double wave_sum(double v)
     v += bnr_dpp_f64(v, 3);
     return (bnr_readlane_c(v, 0) + bnr_readlane_c(v, 16)) + (bnr_readlane_c(v, 32) + bnr_readlane_c(v, 48));
 }
+// wave-level LDS hand-off: a ds_write is not ordered before later ds_reads of the same wave without this wait (measured)
+__device__ __forceinline__ void bnr_wsync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 // sum over each aligned group of 32 lanes (result in every lane of the group)
 __device__ __forceinline__ double half_wave_sum(double v)
 {
@@ -869,21 +871,30 @@ __global__ __launch_bounds__(256) void k_backproj(bnr_dev cd, int s, int flags)
     BNR_BSTAMP(2);
     if (!(flags & 4)) { if (cap) atomicAdd((unsigned long long *)&cd.counters[2], 1ull); return; }
     double *ps = cd.Psum + (size_t)blockIdx.x * (1 + 3 * R);
-    double ssum = wave_sum(act ? Snew : 0.0);
-    if (lane == 0) ps[0] = ssum;
+    // per-edge terms go through LDS ([term][lane], lane-contiguous) and lane j then sums term j over the 32 edges in a
+    // fixed order: one pass instead of 3R+1 wave reductions
+    double *st = sh;                                  // reuse the a4 staging area: (3R + 1) x 33 doubles <= n_pad + 64
     const double *un = row + cd.o_u, *lamp = prev + cd.o_lam;
     const double sd = sqrt(tau2 * Snew), lsd = log(sd) + 0.5 * log(2.0 * BNR_PI);
-    for (int r = 0; r < R; ++r) {
-        double dr = act ? un[r + R * l] * un[r + R * k] : 0.0;
-        double lr = lamp[r];
+    if (lane < 32) {
+        st[lane] = act ? Snew : 0.0;
+        for (int r = 0; r < R; ++r) {
+            double dr = act ? un[r + R * l] * un[r + R * k] : 0.0;
+            double lr = lamp[r];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double Wc = W + (bnr_lambda_value(c) - lr) * dr;
-            double zz = (gam - Wc) / sd;
-            double term = act ? (-0.5 * zz * zz - lsd) : 0.0;
-            term = wave_sum(term);
-            if (lane == 0) ps[1 + 3 * r + c] = term;
+            for (int c = 0; c < 3; ++c) {
+                double Wc = W + (bnr_lambda_value(c) - lr) * dr;
+                double zz = (gam - Wc) / sd;
+                st[(1 + 3 * r + c) * 33 + lane] = act ? (-0.5 * zz * zz - lsd) : 0.0;
+            }
         }
+    }
+    bnr_wsync();
+    for (int j = lane; j < 1 + 3 * R; j += 64) {
+        double acc = 0.0;
+#pragma unroll 8
+        for (int e2 = 0; e2 < 32; ++e2) acc += st[j * 33 + e2];
+        ps[j] = acc;
     }
     BNR_BSTAMP(3);
     if (cap) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
@@ -896,7 +907,6 @@ __global__ __launch_bounds__(256) void k_backproj(bnr_dev cd, int s, int flags)
 // xg_src: 0 = cd.xg (from k_solve_gemv); 1 = sum of the PG partials (X*gamma by k_xpass bit2).
 // Independent scalar draws sit on different wavefronts so that their long scalar sampler code runs concurrently; the
 // small R x R matrix work runs on single wavefronts with wave-level synchronisation only (no block barriers).
-__device__ __forceinline__ void bnr_wsync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 
 // in-place lower Cholesky of an LDS matrix by ONE wavefront (all 64 lanes call); returns 0 ok / 1 not positive definite
 __device__ inline int wave_chol(double *A, int R, int lane)

@@ -122,67 +122,64 @@ BNR_HD double bnr_gig(uint64_t seed, double lambda, double chi, double psi, uint
     const double lambda_old = lambda;
     if (lambda < 0.0) lambda = -lambda;
     const double alpha = sqrt(chi / psi), omega = sqrt(psi * chi);
-    if (lambda > 2.0 || omega > 3.0) {
-        // gig_ROU_shift, gig.jl:44-78
+    const bool shift = (lambda > 2.0 || omega > 3.0);
+    if (shift || lambda >= 1.0 - 2.25 * (omega * omega) || omega > 0.2) {
+        // gig_ROU_shift (gig.jl:44-78) and gig_ROU_noshift (gig.jl:80-100) share one rejection loop:
+        //   U = ulo + ru (uhi - ulo), X = U / V + xoff;  no-shift is (ulo, uhi, xoff) = (0, um, 0), bit-identical to um*ru, U/V.
+        // One loop instead of two keeps a wavefront whose lanes are split over the branches from running them back to back.
         double t = 0.5 * (lambda - 1.0), s = 0.25 * omega;
         double xm = bnr_gig_mode(lambda, omega);
         double nc = t * log(xm) - s * (xm + 1.0 / xm);
-        double a = -(2.0 * (lambda + 1.0) / omega + xm);
-        double b = (2.0 * (lambda - 1.0) * xm / omega - 1.0);
-        double c = xm;
-        double p = b - a * a / 3.0;
-        double q = 2.0 * a * a * a / 27.0 - a * b / 3.0 + c;
-        double fi = acos(-q / (2.0 * sqrt(-p * p * p / 27.0)));
-        double fak = 2.0 * sqrt(-p / 3.0);
-        double y1 = fak * cos(fi / 3.0) - a / 3.0;
-        double y2 = fak * cos(fi / 3.0 + 4.0 / 3.0 * BNR_PI) - a / 3.0;
-        double uplus = (y1 - xm) * exp(t * log(y1) - s * (y1 + 1.0 / y1) - nc);
-        double uminus = (y2 - xm) * exp(t * log(y2) - s * (y2 + 1.0 / y2) - nc);
+        double ulo, uhi, xoff;
+        if (shift) {
+            double a = -(2.0 * (lambda + 1.0) / omega + xm);
+            double b = (2.0 * (lambda - 1.0) * xm / omega - 1.0);
+            double c = xm;
+            double p = b - a * a / 3.0;
+            double q = 2.0 * a * a * a / 27.0 - a * b / 3.0 + c;
+            double fi = acos(-q / (2.0 * sqrt(-p * p * p / 27.0)));
+            double fak = 2.0 * sqrt(-p / 3.0);
+            double y1 = fak * cos(fi / 3.0) - a / 3.0;
+            double y2 = fak * cos(fi / 3.0 + 4.0 / 3.0 * BNR_PI) - a / 3.0;
+            uhi = (y1 - xm) * exp(t * log(y1) - s * (y1 + 1.0 / y1) - nc);
+            ulo = (y2 - xm) * exp(t * log(y2) - s * (y2 + 1.0 / y2) - nc);
+            xoff = xm;
+        } else {
+            double ym = ((lambda + 1.0) + sqrt((lambda + 1.0) * (lambda + 1.0) + omega * omega)) / omega;
+            uhi = exp(0.5 * (lambda + 1.0) * log(ym) - s * (ym + 1.0 / ym) - nc);
+            ulo = 0.0;
+            xoff = 0.0;
+        }
         for (uint32_t k = 0; k < BNR_MAX_ATTEMPTS; ++k) {
             double ru, rv;
             bnr_draw2(seed, it, SITE_D_GIG, elem, k, ru, rv);
-            double U = uminus + ru * (uplus - uminus);
-            double X = U / rv + xm;
+            double U = ulo + ru * (uhi - ulo);
+            double X = U / rv + xoff;
             if (X > 0.0 && log(rv) <= t * log(X) - s * (X + 1.0 / X) - nc)
                 return lambda_old < 0.0 ? alpha / X : alpha * X;
         }
         if (cap) *cap = 1;
         return alpha * xm;
     }
-    if (lambda >= 1.0 - 2.25 * (omega * omega) || omega > 0.2) {
-        // gig_ROU_noshift, gig.jl:80-100
-        double t = 0.5 * (lambda - 1.0), s = 0.25 * omega;
-        double xm = bnr_gig_mode(lambda, omega);
-        double nc = t * log(xm) - s * (xm + 1.0 / xm);
-        double ym = ((lambda + 1.0) + sqrt((lambda + 1.0) * (lambda + 1.0) + omega * omega)) / omega;
-        double um = exp(0.5 * (lambda + 1.0) * log(ym) - s * (ym + 1.0 / ym) - nc);
-        for (uint32_t k = 0; k < BNR_MAX_ATTEMPTS; ++k) {
-            double ru, rv;
-            bnr_draw2(seed, it, SITE_D_GIG, elem, k, ru, rv);
-            double U = um * ru;
-            double X = U / rv;
-            if (log(rv) <= (t * log(X) - s * (X + 1.0 / X) - nc))
-                return lambda_old < 0.0 ? alpha / X : alpha * X;
-        }
-        if (cap) *cap = 1;
-        return alpha * xm;
-    }
     if (lambda >= 0.0 && omega > 0.0) {
-        // gig_concave, gig.jl:102-168
+        // gig_concave, gig.jl:102-168.  For lambda = 1/2 (the only value update_D! uses) the powers are square roots.
+        const bool half = (lambda == 0.5);
         double xm = bnr_gig_mode(lambda, omega);
         double x0 = omega / (1.0 - lambda);
         double k0 = exp((lambda - 1.0) * log(xm) - 0.5 * omega * (xm + 1.0 / xm));
         double A0, A1, A2, k1, k2;
         A0 = k0 * x0;
+        const double x0l = half ? sqrt(x0) : pow(x0, lambda);                 // x0^lambda
         if (x0 >= 2.0 / omega) {
             k1 = 0.0; A1 = 0.0;
-            k2 = pow(x0, lambda - 1.0);
+            k2 = half ? 1.0 / x0l : pow(x0, lambda - 1.0);
             A2 = k2 * 2.0 * exp(-omega * x0 / 2.0) / omega;
         } else {
             k1 = exp(-omega);
+            const double tw = 2.0 / omega, twl = half ? sqrt(tw) : pow(tw, lambda);
             if (lambda == 0.0) A1 = k1 * log(2.0 / (omega * omega));
-            else A1 = k1 / lambda * (pow(2.0 / omega, lambda) - pow(x0, lambda));
-            k2 = pow(2.0 / omega, lambda - 1.0);
+            else A1 = k1 / lambda * (twl - x0l);
+            k2 = half ? 1.0 / twl : pow(tw, lambda - 1.0);
             A2 = k2 * 2.0 * exp(-1.0) / omega;
         }
         double Atot = A0 + A1 + A2;
@@ -195,7 +192,8 @@ BNR_HD double bnr_gig(uint64_t seed, double lambda, double chi, double psi, uint
                 Vv -= A0;
                 if (Vv <= A1) {
                     if (lambda == 0.0) { X = omega * exp(exp(omega) * Vv); hx = k1 / X; }
-                    else { X = pow(pow(x0, lambda) + (lambda / k1 * Vv), 1.0 / lambda); hx = k1 * pow(X, lambda - 1.0); }
+                    else if (half) { double r = x0l + (lambda / k1 * Vv); X = r * r; hx = k1 / r; }
+                    else { X = pow(x0l + (lambda / k1 * Vv), 1.0 / lambda); hx = k1 * pow(X, lambda - 1.0); }
                 } else {
                     Vv -= A1;
                     double a = (x0 > 2.0 / omega) ? x0 : 2.0 / omega;
