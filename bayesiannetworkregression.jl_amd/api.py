@@ -193,6 +193,11 @@ class ChainSet:
         self.ids = local_chain_ids(num_chains)
         dev = _default_device() if device is None else device
         self.chains = {c: Chain(X_new, y, R, tot_save, seed, c, device=dev, **hyper) for c in self.ids}
+        if len(self.chains) > 1:
+            # several chains share this GPU: they overlap EACH OTHER across streams; the intra-chain two-stream schedule would
+            # only oversubscribe the hardware queues (measured: 2 chains 5.9k it/s on one stream each vs 3.9k with two each)
+            for ch in self.chains.values():
+                ch.set_option("overlap", 0)
         self.V, self.q, self.R = (next(iter(self.chains.values())).V, next(iter(self.chains.values())).q, R) if self.chains else (None, None, R)
 
     def init_prior(self):

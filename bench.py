@@ -80,6 +80,8 @@ def main():
     for lc in range(C):
         cid = rank * C + lc + 1                                   # chain c uses stream seed + c (gibbs.jl:928)
         ch = bnr_amd.Chain(X, y, R, tot, a.seed, cid, device=local_rank)
+        if C > 1:
+            ch.set_option("overlap", 0)       # chains overlap each other across streams; see api.ChainSet
         ch.init_prior()
         chains.append(ch)
 
@@ -133,6 +135,10 @@ def main():
         total_chains = world * C
         value = total_chains * K / dt
         flops_gram = float(n) * n * q                             # algorithmic: symmetric X diag(S) X' 
+        traffic = None                                            # HBM bytes per k_gram launch from the PMC passes (tools/pmc_gram2.sh)
+        pmc_file = os.path.join(ROOT, "profiles", "round1_gram_pmc.json")
+        if a.config == "cfg3" and os.path.exists(pmc_file):
+            traffic = json.load(open(pmc_file)).get("traffic_bytes_per_launch")
         achieved = flops_gram / (gram_us * 1e-6) / 1e12 if gram_us > 0 else 0.0
         out = {
             "metric": "Gibbs iterations/sec (all chains)", "value": value, "unit": "iterations/s",
@@ -142,7 +148,9 @@ def main():
                        "chains_per_gpu": C, "seed": a.seed},
             "roofline": {"bound": "mfma", "kernel": "k_gram (X diag(S) X', v_mfma_f64_16x16x4_f64)", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "flops_per_launch": flops_gram, "avg_launch_us": gram_us, "launches_timed": gram_n},
+                         "traffic": traffic, "traffic_source": "profiles/round1_gram_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
+                         "flops_per_launch": flops_gram, "avg_launch_us": gram_us, "launches_timed": gram_n,
+                         "peak_measured_microbench": 70.0},
             "max_rhat_gamma": float(np.nanmax(rh[:q])), "max_rhat_xi": float(np.nanmax(rh[q:])),
             "counters": counters,
         }
