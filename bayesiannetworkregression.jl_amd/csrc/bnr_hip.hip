@@ -221,7 +221,7 @@ int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const dou
     TRY(dev_alloc(c, &d.Minv, BNR_RMAX * BNR_RMAX + 1));
     TRY(dev_alloc(c, &d.Psum, (size_t)d.nblk_bp * (1 + 3 * R)));
     TRY(dev_alloc(c, &d.counters, 16));
-    TRY(dev_alloc(c, &d.stamp, 4 * ntl));
+    TRY(dev_alloc(c, &d.stamp, 8 * ntl));
     TRY(dev_alloc(c, &d.dbg, 1024));
     c->plan_cap = 1 << 16;
     TRY(dev_alloc(c, &c->plan_dev, c->plan_cap));
@@ -305,7 +305,7 @@ static void launch_gram(bnr_chain *c, int s, hipStream_t st, bool timed)
     }
     hipLaunchKernelGGL(k_gram, dim3(ntl * d.ksplit), dim3(1024), 0, st, c->d, s);
     if (timed) hipEventRecord(e1, st);
-    hipLaunchKernelGGL(k_gram_reduce, dim3(ntl, 4), dim3(256), 0, st, c->d, s);
+    hipLaunchKernelGGL(k_gram_reduce, dim3(ntl, 8), dim3(256), 0, st, c->d, s);
 }
 static void launch_rhs(bnr_chain *c, int s) { hipLaunchKernelGGL(k_rhs, dim3(c->d.n_pad / 64), dim3(256), 0, c->stream, c->d, s); }
 static void launch_chol(bnr_chain *c, int s, hipStream_t st)

@@ -518,28 +518,34 @@ __host__ __device__ inline int bnr_ldE(int n_pad) { return 2 * n_pad + BNR_NB; }
 
 __global__ __launch_bounds__(256) void k_gram_reduce(bnr_dev cd, int s)
 {
+    // grid = (lower tiles, 8): each workgroup sums 512 elements (one 16-byte pair per thread) of one tile over the K slices
     int t = blockIdx.x, ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     int tj = t - ti * (ti + 1) / 2;
     const int ntl = cd.ntile * (cd.ntile + 1) / 2;
     const size_t ld = bnr_ldE(cd.n_pad), tsz = BNR_GT * BNR_GT;
-    const int idx0 = blockIdx.y * (BNR_GT * BNR_GT / 4);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        int idx = idx0 + u * 256 + threadIdx.x;
-        double sacc = 0.0;
-        for (int ks = 0; ks < cd.ksplit; ++ks) sacc += cd.Gpart[((size_t)ks * ntl + t) * tsz + idx];
-        int i = ti * BNR_GT + idx % BNR_GT, j = tj * BNR_GT + idx / BNR_GT;
-        if (i == j) sacc += 1.0;
-        cd.E[(size_t)i + ld * j] = sacc;
+    const int idx = blockIdx.y * 512 + 2 * threadIdx.x;            // even: (idx, idx+1) are two consecutive rows i
+    const double *src = cd.Gpart + (size_t)t * tsz + idx;
+    bnr_d2 acc = {0.0, 0.0};
+    int ks = 0;
+    for (; ks + 3 < cd.ksplit; ks += 4) {
+        bnr_d2 v0 = *(const bnr_d2 *)(src + (size_t)ks * ntl * tsz), v1 = *(const bnr_d2 *)(src + (size_t)(ks + 1) * ntl * tsz);
+        bnr_d2 v2 = *(const bnr_d2 *)(src + (size_t)(ks + 2) * ntl * tsz), v3 = *(const bnr_d2 *)(src + (size_t)(ks + 3) * ntl * tsz);
+        acc += v0; acc += v1; acc += v2; acc += v3;
     }
-    // Y = I (all n_pad x n_pad entries), spread over the whole grid
+    for (; ks < cd.ksplit; ++ks) acc += *(const bnr_d2 *)(src + (size_t)ks * ntl * tsz);
+    const int i = ti * BNR_GT + idx % BNR_GT, j = tj * BNR_GT + idx / BNR_GT;
+    if (i == j) acc[0] += 1.0;
+    if (i + 1 == j) acc[1] += 1.0;
+    *(bnr_d2 *)(cd.E + (size_t)i + ld * j) = acc;
+    // Y = I (all n_pad x n_pad entries), spread over the whole grid, 16 bytes per store
     const int nwg = gridDim.x * gridDim.y, wg = blockIdx.x * gridDim.y + blockIdx.y, np = cd.n_pad;
-    for (size_t e = (size_t)wg * 256 + threadIdx.x; e < (size_t)np * np; e += (size_t)nwg * 256) {
+    for (size_t e = ((size_t)wg * 256 + threadIdx.x) * 2; e < (size_t)np * np; e += (size_t)nwg * 512) {
         int r = (int)(e % np), c = (int)(e / np);
-        cd.E[(size_t)(np + r) + ld * c] = (r == c) ? 1.0 : 0.0;
+        bnr_d2 v = {(r == c) ? 1.0 : 0.0, (r + 1 == c) ? 1.0 : 0.0};
+        *(bnr_d2 *)(cd.E + (size_t)(np + r) + ld * c) = v;
     }
-    if (threadIdx.x == 0) cd.stamp[blockIdx.x * 4 + blockIdx.y] = cd.plan[cd.pbase[0] + s].it;
+    if (threadIdx.x == 0) cd.stamp[blockIdx.x * 8 + blockIdx.y] = cd.plan[cd.pbase[0] + s].it;
 }
 
 // ===================================================================================== blocked Cholesky + solve
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(bnr_dev cd, int p, int s)
     if (p == 0 && b == 0) {
         // cheap safety net for the two-branch schedule: every k_gram_reduce workgroup of THIS sweep must have finished
         const unsigned int it = cd.plan[cd.pbase[0] + s].it;
-        const int nred = 4 * (cd.ntile * (cd.ntile + 1) / 2);
+        const int nred = 8 * (cd.ntile * (cd.ntile + 1) / 2);
         for (int w = tid; w < nred; w += blockDim.x)
             if (cd.stamp[w] != it) atomicAdd((unsigned long long *)&cd.counters[8], 1ull);
     }

@@ -310,3 +310,82 @@ def test_headline_size_properties(gpu):
     assert_tables_close(A, o.t, rows_got=slice(0, 4), what="headline first rows")
     for ch in (a, b, c):
         ch.close()
+
+
+def test_launch_modes_are_equivalent(gpu, test1):
+    """Captured hipGraph batches + two-branch schedule (default), eager launches, and the single-stream schedule are
+    different ways to issue the same kernels: the traces must be bitwise equal."""
+    X, y = test1
+    ref = None
+    for opts in ({}, {"graph": 0}, {"overlap": 0}, {"graph": 0, "overlap": 0}, {"graph_k": 3}):
+        ch = bnr_amd.Chain(X, y, 5, 40, 31, 1)
+        for k, v in opts.items():
+            ch.set_option(k, v)
+        ch.init_prior()
+        ch.run(2, 40, 40)
+        got = ch.fetch()
+        assert ch.counters()["chol_fail"] == 0
+        if ref is None:
+            ref = got
+        else:
+            for k in bo.COLUMNS:
+                assert np.array_equal(got[k], ref[k]), (opts, k)
+        ch.close()
+
+
+def test_progress_callback_ticks_like_run(gpu, test1):
+    """Chain 1 ticks every prog_freq iterations (gibbs.jl:854-856); the trace does not depend on the tick frequency."""
+    X, y = test1
+    ticks = []
+    a = bnr_amd.Chain(X, y, 5, 50, 8, 1)
+    a.init_prior()
+    a.run(2, 50, 50, prog_freq=10, callback=lambda done: ticks.append(done))
+    assert ticks == [9, 19, 29, 39, 49]          # i = 10, 20, ... completed -> iterations done so far in this call
+    b = bnr_amd.Chain(X, y, 5, 50, 8, 1)
+    b.init_prior()
+    b.run(2, 50, 50)
+    A, B = a.fetch(), b.fetch()
+    for k in bo.COLUMNS:
+        assert np.array_equal(A[k], B[k]), k
+    a.close()
+    b.close()
+
+
+_RANK_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch.distributed as dist
+import bnr_amd
+rank = int(sys.argv[1]); os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
+dist.init_process_group("gloo", rank=rank, world_size=2)
+d = np.load({data!r}); X, y = d["X"], d["y"]
+keep = []
+res = bnr_amd.generate_samples(X, y, 5, nburn=30, nsamp=20, maxburn=30, psrf_cutoff=1.2, x_transform=False, suppress_timer=True,
+                               num_chains=3, seed=77, device=0, _keep=keep)
+assert sorted(keep[0].chains) == ([1, 3] if rank == 0 else [2])
+np.savez(sys.argv[3] + ".%d.npz" % rank, rg=res.rhatgamma, rx=res.rhatxi, has_state=np.array(res.state is not None),
+         **{{"g%d" % c: ch.fetch(31, 50)["gamma"] for c, ch in keep[0].chains.items()}})
+keep[0].close(); dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_chains_sharded_over_two_ranks(gpu, tmp_path):
+    """Two processes (one per rank, both on this box's GPU, gloo for the exchange): chains 1..3 are sharded round-robin,
+    each rank samples its chains on the device, the per-chain Rhat messages are all-gathered and every rank finishes
+    the same Rhat, equal to rhat() over all three chains."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_WORKER.format(root=root, data=os.path.join(G, "test1_xy.npz")))
+    out = str(tmp_path / "o")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(port), out]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    assert np.array_equal(r0["rg"], r1["rg"]) and np.array_equal(r0["rx"], r1["rx"])
+    assert bool(r0["has_state"]) and not bool(r1["has_state"])          # only chain 1's trace is returned (gibbs.jl:788)
+    allg = np.stack([r0["g1"][:, :, 0], r1["g2"][:, :, 0], r0["g3"][:, :, 0]], axis=2)
+    assert np.allclose(r0["rg"], bo.rhat(allg), rtol=1e-10)
