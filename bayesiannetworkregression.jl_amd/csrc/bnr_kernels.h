@@ -603,10 +603,48 @@ __device__ __forceinline__ bnr_d4 bnr_tile_update(const double *colrows, const d
     return c;
 }
 
+// Register-resident sweep of 16 panel columns, lane = row (64 rows): column j's pivot sits in lane COFF + j.
+// Software pipelined: the next two columns are updated at once through v_readlane broadcasts, the remaining ones one step
+// later with LDS broadcast reads of the published column (sCol, double buffered), so that the LDS latency hides behind the
+// next pivot's rsqrt chain.  (Measured on gfx950: a ds_write is NOT ordered before later ds_reads of the same wave
+// without an s_waitcnt.)
+template <int COFF>
+__device__ __forceinline__ int bnr_sweep16(double (&a)[16], int lane, double (*sCol)[BNR_NB])
+{
+    int bad = 0;
+    double lprev = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double tk[16];
+        if (j >= 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = j + 2; k < 16; ++k) tk[k] = sCol[(j - 1) & 1][COFF + k];
+        }
+        double piv = bnr_readlane(a[j], COFF + j);
+        if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
+        double rinv = bnr_rsqrt(piv);
+        double lj = a[j] * rinv;
+        a[j] = lj;
+        if (j + 1 < 16) a[j + 1] = fma(-lj, bnr_readlane(lj, COFF + j + 1), a[j + 1]);
+        if (j + 2 < 16) a[j + 2] = fma(-lj, bnr_readlane(lj, COFF + j + 2), a[j + 2]);
+        if (lane < 32) sCol[j & 1][lane] = lj;
+        if (j >= 1) {
+#pragma unroll
+            for (int k = j + 2; k < 16; ++k) a[k] = fma(-lprev, tk[k], a[k]);
+        }
+        lprev = lj;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return bad;
+}
+
+#define BNR_L1S 80            // LDS column stride of the 64 x 16 half-panel handed to the MFMA update (conflict-free fragments)
 __global__ __launch_bounds__(256, 1) void k_chol_step(bnr_dev cd, int p, int s)
 {
     __shared__ double sD[BNR_NB * BNR_LP], sB[BNR_NB * BNR_LP];
     __shared__ double sCol[2][BNR_NB];
+    __shared__ double sL1[16 * BNR_L1S];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nbk = cd.n_pad / BNR_NB;
     const size_t ld = bnr_ldE(cd.n_pad);
     const int npanel = bnr_chol_npanel(nbk, p);
@@ -675,48 +713,48 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(bnr_dev cd, int p, int s)
     }
     __syncthreads();
     BNR_STAMP(2);
+    // Panel sweep in two halves of 16 columns (lane = row: lanes 0..31 rows of the diagonal block, lanes 32..63 rows of the
+    // own block); between them the second half is updated with the first by f64 MFMA on all four waves:
+    //   A[:, 16:32] -= L[:, 0:16] L[16:32, 0:16]'
+    const int rr = lane & 31;
+    double a1[16], a2[16];
+    int bad = 0;
     if (wave == 0) {
-        // panel sweep, lane = row: lanes 0..31 rows of the diagonal block, lanes 32..63 rows of the own block
-        const int rr = lane & 31;
         const double *src = (lane < 32) ? sD : sB;
-        double a[BNR_NB];
 #pragma unroll
-        for (int c = 0; c < BNR_NB; ++c) a[c] = src[rr + BNR_LP * c];
-        int bad = 0;
-        double lprev = 0.0;
+        for (int c = 0; c < 16; ++c) a1[c] = src[rr + BNR_LP * c];
+        bad = bnr_sweep16<0>(a1, lane, sCol);
 #pragma unroll
-        for (int j = 0; j < BNR_NB; ++j) {
-            // (A) issue the LDS broadcast reads for the lagged tail of column j-1: its entries k = j+2 .. NB-1
-            // (measured on gfx950: a ds_write is NOT ordered before later ds_reads of the same wave without this wait)
-            double tk[BNR_NB];
-            if (j >= 1) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int c = 0; c < 16; ++c) sL1[c * BNR_L1S + lane] = a1[c];
+    }
+    __syncthreads();
+    {
+        // wave w owns rows 16 w .. 16 w + 15 of the 64-row panel
+        double *sx = (wave < 2) ? sD : sB;
+        const int rowb = (wave & 1) * 16;
+        bnr_d4 c;
 #pragma unroll
-                for (int k = j + 2; k < BNR_NB; ++k) tk[k] = sCol[(j - 1) & 1][k];
-            }
-            // (B) pivot chain of column j
-            double piv = bnr_readlane(a[j], j);
-            if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
-            double rinv = bnr_rsqrt(piv);
-            double lj = a[j] * rinv;
-            a[j] = lj;
-            // (C) the next two columns right away
-            if (j + 1 < BNR_NB) a[j + 1] = fma(-lj, bnr_readlane(lj, j + 1), a[j + 1]);
-            if (j + 2 < BNR_NB) a[j + 2] = fma(-lj, bnr_readlane(lj, j + 2), a[j + 2]);
-            // (D) publish column j of the diagonal block for the lagged tail
-            if (lane < 32) sCol[j & 1][lane] = lj;
-            // (E) lagged tail of column j-1
-            if (j >= 1) {
+        for (int r = 0; r < 4; ++r) c[r] = sx[(rowb + ln) + BNR_LP * (16 + lq + 4 * r)];
 #pragma unroll
-                for (int k = j + 2; k < BNR_NB; ++k) a[k] = fma(-lprev, tk[k], a[k]);
-            }
-            lprev = lj;
+        for (int ks = 0; ks < 4; ++ks) {
+            double av = sL1[(4 * ks + lq) * BNR_L1S + 16 + ln];            // column side: rows 16..31 of the diagonal part
+            double bv = sL1[(4 * ks + lq) * BNR_L1S + 16 * wave + ln];     // row side
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av, bv, c, 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sx[(rowb + ln) + BNR_LP * (16 + lq + 4 * r)] = c[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const double *src = (lane < 32) ? sD : sB;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a2[c] = src[rr + BNR_LP * (16 + c)];
+        bad |= bnr_sweep16<16>(a2, lane, sCol);
         if (bad && lane == 0 && b == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[7], 1ull); }
         // hand the swept own block back through LDS (the factored diagonal block is not needed by anybody later)
         if (lane >= 32) {
 #pragma unroll
-            for (int c = 0; c < BNR_NB; ++c) sB[rr + BNR_LP * c] = a[c];
+            for (int c = 0; c < 16; ++c) { sB[rr + BNR_LP * c] = a1[c]; sB[rr + BNR_LP * (16 + c)] = a2[c]; }
         }
     }
     __syncthreads();
