@@ -640,11 +640,73 @@ __device__ __forceinline__ int bnr_sweep16(double (&a)[16], int lane, double (*s
 }
 
 #define BNR_L1S 80            // LDS column stride of the 64 x 16 half-panel handed to the MFMA update (conflict-free fragments)
+struct bnr_panel_lds {
+    double sD[BNR_NB * BNR_LP], sB[BNR_NB * BNR_LP];
+    double sCol[2][BNR_NB];
+    double sL1[16 * BNR_L1S];
+};
+// Sweep of the 64 x 32 panel [D ; B] by one workgroup of 256 threads: D = updated, unfactored diagonal block, B = own
+// block, both handed over as the MFMA accumulator fragments (mt, nt) of the four waves.  On return sh.sB holds
+// B L_D^-T (column-major, stride BNR_LP); the factored diagonal block is not produced.  Returns (wave 0 only) 1 if a
+// pivot was not positive.
+// Two halves of 16 columns (lane = row: lanes 0..31 rows of the diagonal block, lanes 32..63 rows of the own block);
+// between them the second half is updated with the first by f64 MFMA on all four waves:
+//   A[:, 16:32] -= L[:, 0:16] L[16:32, 0:16]'
+__device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &cD, const bnr_d4 &cB, int tid)
+{
+    const int wave = tid >> 6, lane = tid & 63, mt = wave >> 1, nt = wave & 1, ln = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sh.sD[(nt * 16 + ln) + BNR_LP * (mt * 16 + lq + 4 * r)] = cD[r];
+        sh.sB[(nt * 16 + ln) + BNR_LP * (mt * 16 + lq + 4 * r)] = cB[r];
+    }
+    __syncthreads();
+    const int rr = lane & 31;
+    double a1[16], a2[16];
+    int bad = 0;
+    if (wave == 0) {
+        const double *src = (lane < 32) ? sh.sD : sh.sB;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a1[c] = src[rr + BNR_LP * c];
+        bad = bnr_sweep16<0>(a1, lane, sh.sCol);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sh.sL1[c * BNR_L1S + lane] = a1[c];
+    }
+    __syncthreads();
+    {
+        // wave w owns rows 16 w .. 16 w + 15 of the 64-row panel
+        double *sx = (wave < 2) ? sh.sD : sh.sB;
+        const int rowb = (wave & 1) * 16;
+        bnr_d4 c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = sx[(rowb + ln) + BNR_LP * (16 + lq + 4 * r)];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            double av = sh.sL1[(4 * ks + lq) * BNR_L1S + 16 + ln];            // column side: rows 16..31 of the diagonal part
+            double bv = sh.sL1[(4 * ks + lq) * BNR_L1S + 16 * wave + ln];     // row side
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av, bv, c, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sx[(rowb + ln) + BNR_LP * (16 + lq + 4 * r)] = c[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const double *src = (lane < 32) ? sh.sD : sh.sB;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a2[c] = src[rr + BNR_LP * (16 + c)];
+        bad |= bnr_sweep16<16>(a2, lane, sh.sCol);
+        // hand the swept own block back through LDS (the factored diagonal block is not needed by anybody later)
+        if (lane >= 32) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { sh.sB[rr + BNR_LP * c] = a1[c]; sh.sB[rr + BNR_LP * (16 + c)] = a2[c]; }
+        }
+    }
+    __syncthreads();
+    return bad;
+}
 __global__ __launch_bounds__(256, 1) void k_chol_step(bnr_dev cd, int p, int s)
 {
-    __shared__ double sD[BNR_NB * BNR_LP], sB[BNR_NB * BNR_LP];
-    __shared__ double sCol[2][BNR_NB];
-    __shared__ double sL1[16 * BNR_L1S];
+    __shared__ bnr_panel_lds sh;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nbk = cd.n_pad / BNR_NB;
     const size_t ld = bnr_ldE(cd.n_pad);
     const int npanel = bnr_chol_npanel(nbk, p);
@@ -694,10 +756,10 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(bnr_dev cd, int p, int s)
     int rho;                                               // own block row
     if (b < nbk - p) rho = p + b;                          // matrix rows p..nbk-1
     else rho = nbk + (b - (nbk - p));                      // identity block rows 0..p
+    bnr_d4 cD, cB;
     {
         const double *dp = E + (size_t)(pc + nt * 16 + ln) + ld * (size_t)(pc + mt * 16 + lq);
         const double *bp = E + (size_t)(rho * BNR_NB + nt * 16 + ln) + ld * (size_t)(pc + mt * 16 + lq);
-        bnr_d4 cD, cB;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { cD[r] = dp[ld * (size_t)(4 * r)]; cB[r] = bp[ld * (size_t)(4 * r)]; }
         if (p > 0) {
@@ -705,59 +767,10 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(bnr_dev cd, int p, int s)
             cD = bnr_tile_update(colrows, E + (size_t)(pc + nt * 16) + ld * (size_t)kc, ld, lane, cD);
             cB = bnr_tile_update(colrows, E + (size_t)(rho * BNR_NB + nt * 16) + ld * (size_t)kc, ld, lane, cB);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sD[(nt * 16 + ln) + BNR_LP * (mt * 16 + lq + 4 * r)] = cD[r];
-            sB[(nt * 16 + ln) + BNR_LP * (mt * 16 + lq + 4 * r)] = cB[r];
-        }
     }
-    __syncthreads();
     BNR_STAMP(2);
-    // Panel sweep in two halves of 16 columns (lane = row: lanes 0..31 rows of the diagonal block, lanes 32..63 rows of the
-    // own block); between them the second half is updated with the first by f64 MFMA on all four waves:
-    //   A[:, 16:32] -= L[:, 0:16] L[16:32, 0:16]'
-    const int rr = lane & 31;
-    double a1[16], a2[16];
-    int bad = 0;
-    if (wave == 0) {
-        const double *src = (lane < 32) ? sD : sB;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) a1[c] = src[rr + BNR_LP * c];
-        bad = bnr_sweep16<0>(a1, lane, sCol);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) sL1[c * BNR_L1S + lane] = a1[c];
-    }
-    __syncthreads();
-    {
-        // wave w owns rows 16 w .. 16 w + 15 of the 64-row panel
-        double *sx = (wave < 2) ? sD : sB;
-        const int rowb = (wave & 1) * 16;
-        bnr_d4 c;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) c[r] = sx[(rowb + ln) + BNR_LP * (16 + lq + 4 * r)];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            double av = sL1[(4 * ks + lq) * BNR_L1S + 16 + ln];            // column side: rows 16..31 of the diagonal part
-            double bv = sL1[(4 * ks + lq) * BNR_L1S + 16 * wave + ln];     // row side
-            c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av, bv, c, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sx[(rowb + ln) + BNR_LP * (16 + lq + 4 * r)] = c[r];
-    }
-    __syncthreads();
-    if (wave == 0) {
-        const double *src = (lane < 32) ? sD : sB;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) a2[c] = src[rr + BNR_LP * (16 + c)];
-        bad |= bnr_sweep16<16>(a2, lane, sCol);
-        if (bad && lane == 0 && b == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[7], 1ull); }
-        // hand the swept own block back through LDS (the factored diagonal block is not needed by anybody later)
-        if (lane >= 32) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) { sB[rr + BNR_LP * c] = a1[c]; sB[rr + BNR_LP * (16 + c)] = a2[c]; }
-        }
-    }
-    __syncthreads();
+    const int bad = bnr_panel_sweep(sh, cD, cB, tid);
+    if (bad && tid == 0 && b == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[7], 1ull); }
     BNR_STAMP(3);
     // The factored diagonal block L_pp is needed by nobody after this launch and is NOT written back: every panel
     // workgroup of this launch reads the unfactored block (p,p) whenever it happens to start.
@@ -766,7 +779,7 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(bnr_dev cd, int p, int s)
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) {
             int c = c0 + 8 * mm;
-            E[(size_t)(rho * BNR_NB + r) + ld * (size_t)(pc + c)] = sB[r + BNR_LP * c];
+            E[(size_t)(rho * BNR_NB + r) + ld * (size_t)(pc + c)] = sh.sB[r + BNR_LP * c];
         }
     }
     BNR_STAMP(4);
