@@ -33,12 +33,19 @@ _SIGS = {
     "bnr_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "bnr_chain_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(Hyper), C.c_uint64, C.c_int32,
                                    C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "bnr_chain_create_like": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "bnr_chain_destroy": (C.c_int, [C.c_void_p]),
     "bnr_chain_init_prior": (C.c_int, [C.c_void_p]),
     "bnr_chain_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, PROGRESS_CB, C.c_void_p,
                                 C.POINTER(C.c_int32)]),
     "bnr_chain_run_async": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "bnr_chain_sync": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "bnr_group_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]),
+    "bnr_group_destroy": (C.c_int, [C.c_void_p]),
+    "bnr_group_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, PROGRESS_CB, C.c_void_p,
+                                C.POINTER(C.c_int32)]),
+    "bnr_group_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "bnr_group_last_timing": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "bnr_gibbs_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
     "bnr_chain_get_iter": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "bnr_chain_set_iter": (C.c_int, [C.c_void_p, C.c_int64]),
@@ -135,6 +142,17 @@ class Chain:
         self.L = lib()
         check(self.L.bnr_chain_create(n, V, int(R), _ptr(Xf), _ptr(yf), C.byref(hy), C.c_uint64(int(seed) & (2**64 - 1)),
                                       int(chain_id), int(device), int(tot_save), C.byref(self.h)))
+
+    @classmethod
+    def like(cls, donor, seed, chain_id, tot_save=None):
+        """Another chain of the same fit (same X, y, hyper-parameters; device inputs shared with `donor`)."""
+        self = cls.__new__(cls)
+        self.n, self.q, self.V, self.R = donor.n, donor.q, donor.V, donor.R
+        self.tot = int(donor.tot if tot_save is None else tot_save)
+        self.h = C.c_void_p()
+        self.L = donor.L
+        check(self.L.bnr_chain_create_like(donor.h, C.c_uint64(int(seed) & (2**64 - 1)), int(chain_id), self.tot, C.byref(self.h)))
+        return self
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
@@ -244,6 +262,43 @@ class Chain:
 
     def set_option(self, name, value):
         check(self.L.bnr_chain_set_option(self.h, name.encode(), int(value)))
+
+
+class Group:
+    """Lockstep group of equally shaped chains on one GPU (bnr_group_* of include/bnr_hip.h): one launch per kernel of a
+    sweep for all members; every member's table is bitwise what it would be when run alone."""
+
+    def __init__(self, chains):
+        self.chains = list(chains)
+        self.L = lib()
+        self.h = C.c_void_p()
+        arr = (C.c_void_p * len(self.chains))(*[ch.h for ch in self.chains])
+        check(self.L.bnr_group_create(arr, len(self.chains), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.bnr_group_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def run(self, first_index, nburn, total, purge_burn=None, prog_freq=0, callback=None):
+        nxt = C.c_int32(0)
+        cb = PROGRESS_CB(lambda user, done: callback(done)) if callback else PROGRESS_CB()
+        check(self.L.bnr_group_run(self.h, first_index, nburn, total, purge_burn or 0, prog_freq if callback else 0, cb,
+                                   None, C.byref(nxt)))
+        return nxt.value
+
+    def set_option(self, name, value):
+        check(self.L.bnr_group_set_option(self.h, name.encode(), int(value)))
+
+    def set_profiling(self, on=True):
+        self.set_option("profiling", 1 if on else 0)
+
+    def last_timing(self, which):
+        us, n = C.c_double(0), C.c_int64(0)
+        check(self.L.bnr_group_last_timing(self.h, which, C.byref(us), C.byref(n)))
+        return us.value, n.value
 
 
 def rhat_from_stats(stats, nsamp):

@@ -27,7 +27,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _capi
-from ._capi import Chain, new_table, rhat_from_stats
+from ._capi import Chain, Group, new_table, rhat_from_stats
 
 CITATION = ("If you use BayesianNetworkRegression.jl, please cite:\n@article{Ozminkowski2022,\n"
             "author = {Ozminkowski, S. and Sol\\'{i}s-Lemus, C.},\nyear = {2022},\n"
@@ -192,12 +192,13 @@ class ChainSet:
         self.num_chains = num_chains
         self.ids = local_chain_ids(num_chains)
         dev = _default_device() if device is None else device
-        self.chains = {c: Chain(X_new, y, R, tot_save, seed, c, device=dev, **hyper) for c in self.ids}
-        if len(self.chains) > 1:
-            # several chains share this GPU: they overlap EACH OTHER across streams; the intra-chain two-stream schedule would
-            # only oversubscribe the hardware queues (measured: 2 chains 5.9k it/s on one stream each vs 3.9k with two each)
-            for ch in self.chains.values():
-                ch.set_option("overlap", 0)
+        self.chains = {}
+        for c in self.ids:                                  # X, y are uploaded once per GPU and shared by its chains
+            first = next(iter(self.chains.values()), None)
+            self.chains[c] = Chain(X_new, y, R, tot_save, seed, c, device=dev, **hyper) if first is None else Chain.like(first, seed, c, tot_save)
+        # several chains share this GPU: they advance in lockstep, one launch per kernel for all of them (the sequential
+        # panel chain of the n x n factorization is paid once per sweep of the whole group)
+        self.group = Group([self.chains[c] for c in self.ids]) if len(self.chains) > 1 else None
         self.V, self.q, self.R = (next(iter(self.chains.values())).V, next(iter(self.chains.values())).q, R) if self.chains else (None, None, R)
 
     def init_prior(self):
@@ -205,17 +206,14 @@ class ChainSet:
             ch.init_prior()
 
     def run(self, first_index, nburn, total, purge_burn, prog_freq=0, callback=None):
-        """run! on every local chain; chains overlap on the GPU (async launch, then sync).  Chain 1 ticks the
-        progress callback (gibbs.jl:854-856) and is therefore run synchronously last."""
-        tick = [c for c in self.ids if c == 1 and callback is not None]
-        for c in self.ids:
-            if c not in tick:
-                self.chains[c].run_async(first_index, nburn, total, purge_burn)
-        for c in tick:
-            self.chains[c].run(first_index, nburn, total, purge_burn, prog_freq, callback)
-        for c in self.ids:
-            if c not in tick:
-                self.chains[c].sync()
+        """run! on every local chain (in lockstep when there are several).  The rank that holds chain 1 ticks the
+        progress callback (gibbs.jl:854-856)."""
+        cb = callback if 1 in self.ids else None
+        if self.group is not None:
+            self.group.run(first_index, nburn, total, purge_burn, prog_freq, cb)
+        else:
+            for c in self.ids:
+                self.chains[c].run(first_index, nburn, total, purge_burn, prog_freq, cb if c == 1 else None)
 
     def rhat(self, first_row, nsamp):
         """split-Rhat over ALL chains of the fit for gamma (q) then xi (V) (return_psrf_VOI, gibbs.jl:771-789)."""
@@ -231,6 +229,8 @@ class ChainSet:
         return int(round((-3 + math.sqrt(9 + 8 * npar)) / 2))
 
     def close(self):
+        if self.group is not None:
+            self.group.close()
         for ch in self.chains.values():
             ch.close()
 

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -20,13 +21,39 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
             return fail(BNR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));               \
     } while (0)
 
-struct bnr_chain {
-    bnr_dev d{};
+// Where and how sweeps are issued: ONE chain, or a lockstep group of equally shaped chains whose kernels are launched
+// together (blockIdx.z = member).  Kernels read their chain's bnr_dev from the device array `cds`.
+struct bnr_exec {
     int device = 0;
+    int nb = 1;                                         // chains issued together
+    bnr_dev *cds = nullptr;                             // device array of nb structs
+    const bnr_dev *shape = nullptr;                     // host struct of member 0 (sizes are equal for all members)
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: the Gram branch of a sweep
     std::vector<hipEvent_t> fj;                         // fork/join events
     size_t fj_next = 0;
     int overlap = 1;
+    int use_graph = 1, graph_k = 8;
+    hipGraphExec_t gexec = nullptr;
+    hipGraph_t graph = nullptr;
+    // profiling
+    int profiling = 0;
+    std::vector<hipEvent_t> ev;  // pairs around k_gram
+    double t_gram_us = 0, t_iter_us = 0, t_gram_acc = 0;
+    int64_t n_gram = 0, n_iter = 0;
+};
+
+// read-only device inputs of a fit (model matrix, response, edge maps, Gram task map): shared by the chains created
+// with bnr_chain_create_like, freed with the last of them
+struct bnr_inputs {
+    std::vector<void *> bufs;
+    ~bnr_inputs() { for (void *p : bufs) hipFree(p); }
+};
+
+struct bnr_chain {
+    bnr_dev d{};
+    std::shared_ptr<bnr_inputs> in;
+    bnr_exec x;                  // issues this chain alone
+    int device = 0;
     std::vector<void *> allocs;
     bnr_plan_entry *plan_dev = nullptr, *plan_pin = nullptr;
     int plan_cap = 0;
@@ -36,16 +63,13 @@ struct bnr_chain {
     bool pending = false;
     long long *counters_host = nullptr;
     int *pbase_dev = nullptr;
-    // options
-    int use_graph = 1, graph_k = 8;
-    hipGraphExec_t gexec = nullptr;
-    hipGraph_t graph = nullptr;
-    // profiling
-    int profiling = 0;
-    std::vector<hipEvent_t> ev;  // pairs around k_gram, plus [begin,end] of the run
-    double t_gram_us = 0, t_iter_us = 0, t_gram_acc = 0;
-    int64_t n_gram = 0, n_iter = 0;
     size_t trace_bytes = 0;
+    struct bnr_group *group = nullptr;   // lockstep group this chain belongs to (at most one)
+};
+
+struct bnr_group {
+    std::vector<bnr_chain *> m;
+    bnr_exec x;                  // issues all members together
 };
 
 static int round_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -67,6 +91,10 @@ static void forget_alloc(bnr_chain *c, void *p)
 }
 
 extern "C" {
+
+static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape);
+static void exec_free(bnr_exec &x);
+static int sync_dev(bnr_chain *c);
 
 int bnr_abi_version(void) { return BNR_ABI_VERSION; }
 const char *bnr_last_error(void) { return g_err.c_str(); }
@@ -104,10 +132,11 @@ static int alloc_trace(bnr_chain *c, int tot, double **out)
     return BNR_OK;
 }
 
-int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const double *y, const bnr_hyper *hyper,
-                     uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save, bnr_chain **out)
+// donor != NULL: share the donor's device inputs instead of uploading X, y (bnr_chain_create_like)
+static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, const double *X, const double *y, const bnr_hyper *hyper,
+                       uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save, bnr_chain **out)
 {
-    if (!out || !X || !y || !hyper) return fail(BNR_ERR_BAD_ARG, "NULL argument");
+    if (!out || !hyper || (!donor && (!X || !y))) return fail(BNR_ERR_BAD_ARG, "NULL argument");
     if (n < 1 || V < 2 || R < 1 || R > BNR_RMAX || tot_save < 2)
         return fail(BNR_ERR_BAD_ARG, "need n>=1, V>=2, 1<=R<=32, tot_save>=2");
     int ndev = 0;
@@ -162,46 +191,55 @@ int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const dou
     d.nblk_bp = (d.q + d.chunk_bp - 1) / d.chunk_bp;
 
     int rc;
-    double *Xd = nullptr, *yd = nullptr;
-    int *ek = nullptr, *el = nullptr;
 #define TRY(x) do { rc = (x); if (rc) { bnr_chain_destroy(c); return rc; } } while (0)
-    TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess ? BNR_OK : fail(BNR_ERR_HIP, "hipStreamCreate failed"));
-    TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess ? BNR_OK : fail(BNR_ERR_HIP, "hipStreamCreate failed"));
-    TRY(dev_alloc(c, &Xd, (size_t)d.n_pad * (d.q_pad + 64)));       // + 64 zero columns: the Gram prefetch may run 5 batches past a slice
-    TRY(dev_alloc(c, &yd, d.n_pad));
-    TRY(dev_alloc(c, &ek, d.q));
-    TRY(dev_alloc(c, &el, d.q));
-    if (hipMemcpy2D(Xd, (size_t)d.n_pad * sizeof(double), X, (size_t)n * sizeof(double), (size_t)n * sizeof(double), d.q,
-                    hipMemcpyHostToDevice) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "copy X failed"); }
-    if (hipMemcpy(yd, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "copy y failed"); }
-    {
-        std::vector<int> hk(d.q), hl(d.q);
-        int e = 0;
-        for (int k = 0; k < V; ++k) for (int l = k; l < V; ++l, ++e) { hk[e] = k; hl[e] = l; }
-        hipMemcpy(ek, hk.data(), d.q * sizeof(int), hipMemcpyHostToDevice);
-        hipMemcpy(el, hl.data(), d.q * sizeof(int), hipMemcpyHostToDevice);
-    }
-    {
-        // XCD-aware task map of k_gram (tasks = lower tiles x K slices)
-        const int ntask = ntl * d.ksplit;
-        std::vector<int> map(ntask, -1), next_tile(d.ksplit, 0);
-        std::vector<int> later;
-        for (int i = 0; i < ntask; ++i) {
-            int x = i % 8;
-            if (x < d.ksplit && next_tile[x] < ntl) { map[i] = next_tile[x] | (x << 16); next_tile[x]++; }
-            else later.push_back(i);
+    TRY(exec_init(c->x, device, 1, &c->d));
+    if (donor) {
+        c->in = donor->in;
+        d.X = donor->d.X; d.y = donor->d.y; d.ek = donor->d.ek; d.el = donor->d.el; d.gmap = donor->d.gmap;
+    } else {
+        c->in = std::make_shared<bnr_inputs>();
+        double *Xd = nullptr, *yd = nullptr;
+        int *ek = nullptr, *el = nullptr, *gm = nullptr;
+        auto in_alloc = [&](void **ptr, size_t bytes) -> int {
+            HIPCHK(hipMalloc(ptr, std::max<size_t>(bytes, 8)));
+            c->in->bufs.push_back(*ptr);
+            HIPCHK(hipMemset(*ptr, 0, std::max<size_t>(bytes, 8)));
+            return BNR_OK;
+        };
+        TRY(in_alloc((void **)&Xd, sizeof(double) * (size_t)d.n_pad * (d.q_pad + 64)));   // + 64 zero columns: the Gram prefetch may run 5 batches past a slice
+        TRY(in_alloc((void **)&yd, sizeof(double) * d.n_pad));
+        TRY(in_alloc((void **)&ek, sizeof(int) * d.q));
+        TRY(in_alloc((void **)&el, sizeof(int) * d.q));
+        if (hipMemcpy2D(Xd, (size_t)d.n_pad * sizeof(double), X, (size_t)n * sizeof(double), (size_t)n * sizeof(double), d.q,
+                        hipMemcpyHostToDevice) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "copy X failed"); }
+        if (hipMemcpy(yd, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "copy y failed"); }
+        {
+            std::vector<int> hk(d.q), hl(d.q);
+            int e = 0;
+            for (int k = 0; k < V; ++k) for (int l = k; l < V; ++l, ++e) { hk[e] = k; hl[e] = l; }
+            hipMemcpy(ek, hk.data(), d.q * sizeof(int), hipMemcpyHostToDevice);
+            hipMemcpy(el, hl.data(), d.q * sizeof(int), hipMemcpyHostToDevice);
         }
-        int ks = 0;
-        for (int i : later) {
-            while (ks < d.ksplit && next_tile[ks] >= ntl) ++ks;
-            map[i] = next_tile[ks] | (ks << 16); next_tile[ks]++;
+        {
+            // XCD-aware task map of k_gram (tasks = lower tiles x K slices)
+            const int ntask = ntl * d.ksplit;
+            std::vector<int> map(ntask, -1), next_tile(d.ksplit, 0);
+            std::vector<int> later;
+            for (int i = 0; i < ntask; ++i) {
+                int x = i % 8;
+                if (x < d.ksplit && next_tile[x] < ntl) { map[i] = next_tile[x] | (x << 16); next_tile[x]++; }
+                else later.push_back(i);
+            }
+            int ks = 0;
+            for (int i : later) {
+                while (ks < d.ksplit && next_tile[ks] >= ntl) ++ks;
+                map[i] = next_tile[ks] | (ks << 16); next_tile[ks]++;
+            }
+            TRY(in_alloc((void **)&gm, sizeof(int) * ntask));
+            hipMemcpy(gm, map.data(), ntask * sizeof(int), hipMemcpyHostToDevice);
         }
-        int *gm = nullptr;
-        TRY(dev_alloc(c, &gm, ntask));
-        hipMemcpy(gm, map.data(), ntask * sizeof(int), hipMemcpyHostToDevice);
-        d.gmap = gm;
+        d.X = Xd; d.y = yd; d.ek = ek; d.el = el; d.gmap = gm;
     }
-    d.X = Xd; d.y = yd; d.ek = ek; d.el = el;
     TRY(alloc_trace(c, tot_save, &d.trace));
     TRY(dev_alloc(c, &d.Wbuf, d.q_pad));
     TRY(dev_alloc(c, &d.sz, d.q_pad));
@@ -230,26 +268,64 @@ int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const dou
     if (hipHostMalloc((void **)&c->plan_pin, sizeof(bnr_plan_entry) * c->plan_cap) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipHostMalloc failed"); }
     if (hipHostMalloc((void **)&c->counters_host, sizeof(long long) * 16) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipHostMalloc failed"); }
     d.plan = c->plan_dev;
+    TRY(sync_dev(c));
 #undef TRY
     *out = c;
     return BNR_OK;
 }
 
-static void drop_graph(bnr_chain *c)
+int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const double *y, const bnr_hyper *hyper,
+                     uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save, bnr_chain **out)
+{ return chain_build(nullptr, n, V, R, X, y, hyper, seed, chain_id, device, tot_save, out); }
+
+int bnr_chain_create_like(const bnr_chain *donor, uint64_t seed, int32_t chain_id, int32_t tot_save, bnr_chain **out)
 {
-    if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
-    if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+    if (!donor) return fail(BNR_ERR_BAD_ARG, "NULL donor chain");
+    const bnr_dev &a = donor->d;
+    bnr_hyper h{a.eta, a.zeta, a.iota, a.aDelta, a.bDelta, a.nu};
+    return chain_build(donor, a.n, a.V, a.R, nullptr, nullptr, &h, seed, chain_id, donor->device, tot_save, out);
 }
+
+static void drop_graph(bnr_exec &x)
+{
+    if (x.gexec) { hipGraphExecDestroy(x.gexec); x.gexec = nullptr; }
+    if (x.graph) { hipGraphDestroy(x.graph); x.graph = nullptr; }
+}
+static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape)
+{
+    x.device = device; x.nb = nb; x.shape = shape;
+    HIPCHK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&x.stream2, hipStreamNonBlocking));
+    HIPCHK(hipMalloc((void **)&x.cds, sizeof(bnr_dev) * nb));
+    return BNR_OK;
+}
+static void exec_free(bnr_exec &x)
+{
+    if (x.stream) { hipStreamSynchronize(x.stream); }
+    if (x.stream2) { hipStreamSynchronize(x.stream2); }
+    drop_graph(x);
+    if (x.stream) hipStreamDestroy(x.stream);
+    if (x.stream2) hipStreamDestroy(x.stream2);
+    for (hipEvent_t e : x.fj) hipEventDestroy(e);
+    for (hipEvent_t e : x.ev) hipEventDestroy(e);
+    if (x.cds) hipFree(x.cds);
+    x = bnr_exec();
+}
+// the kernels read the chain's bnr_dev from device memory: refresh the copy whenever the host struct changes
+static int sync_dev(bnr_chain *c)
+{
+    HIPCHK(hipMemcpy(c->x.cds, &c->d, sizeof(bnr_dev), hipMemcpyHostToDevice));
+    return BNR_OK;
+}
+
+int bnr_group_destroy(bnr_group *g);
 
 int bnr_chain_destroy(bnr_chain *c)
 {
     if (!c) return BNR_OK;
     hipSetDevice(c->device);
-    if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
-    if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
-    for (hipEvent_t e : c->fj) hipEventDestroy(e);
-    drop_graph(c);
-    for (hipEvent_t e : c->ev) hipEventDestroy(e);
+    if (c->group) bnr_group_destroy(c->group);          // a group cannot outlive a member
+    exec_free(c->x);
     for (void *p : c->allocs) hipFree(p);
     if (c->d.trace) hipFree(c->d.trace);
     if (c->plan_pin) hipHostFree(c->plan_pin);
@@ -263,7 +339,7 @@ static int ensure_plan(bnr_chain *c, int count)
 {
     if (count <= c->plan_cap) return BNR_OK;
     int cap = std::max(count, 2 * c->plan_cap);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->x.stream));
     bnr_plan_entry *nd = nullptr, *np = nullptr;
     HIPCHK(hipMalloc((void **)&nd, sizeof(bnr_plan_entry) * cap));
     HIPCHK(hipHostMalloc((void **)&np, sizeof(bnr_plan_entry) * cap));
@@ -273,13 +349,13 @@ static int ensure_plan(bnr_chain *c, int count)
     c->allocs.push_back(nd);
     c->plan_dev = nd; c->plan_pin = np; c->plan_cap = cap;
     c->d.plan = nd;
-    drop_graph(c);                       // kernel arguments baked into the captured graph changed
-    return BNR_OK;
+    drop_graph(c->x);                       // one chain: the struct is a by-value kernel argument baked into the captured graph
+    return sync_dev(c);
 }
 static int upload_plan(bnr_chain *c, int count)
 {
-    HIPCHK(hipMemcpyAsync(c->plan_dev, c->plan_pin, sizeof(bnr_plan_entry) * count, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->pbase_dev, 0, sizeof(int), c->stream));
+    HIPCHK(hipMemcpyAsync(c->plan_dev, c->plan_pin, sizeof(bnr_plan_entry) * count, hipMemcpyHostToDevice, c->x.stream));
+    HIPCHK(hipMemsetAsync(c->pbase_dev, 0, sizeof(int), c->x.stream));
     return BNR_OK;
 }
 static int check_launch(const char *what)
@@ -289,47 +365,54 @@ static int check_launch(const char *what)
     return BNR_OK;
 }
 
-static void launch_node(bnr_chain *c, int s, int mode)
-{ hipLaunchKernelGGL(k_node, dim3(c->d.V), dim3(64), 64 * (2 * c->d.R + 1) * sizeof(double), c->stream, c->d, s, mode); }
-static void launch_xpass(bnr_chain *c, int s, int which)
-{ hipLaunchKernelGGL(k_xpass, dim3(c->d.nblk_x), dim3(256), 3 * c->d.chunk_x * sizeof(double), c->stream, c->d, s, which); }
-static void launch_gram(bnr_chain *c, int s, hipStream_t st, bool timed)
+// one chain: struct by value; group: device array (see bnr_one / bnr_many)
+#define BNR_LAUNCH(kern, grid, block, lds, st, x, ...)                                                                     \
+    do {                                                                                                                   \
+        if ((x).nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(kern<bnr_one>), grid, block, lds, st, bnr_one{*(x).shape}, ##__VA_ARGS__);   \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(kern<bnr_many>), grid, block, lds, st, bnr_many{(x).cds}, ##__VA_ARGS__);  \
+    } while (0)
+
+static void launch_node(bnr_exec &x, int s, int mode)
+{ BNR_LAUNCH(k_node, dim3(x.shape->V, 1, x.nb), dim3(64), 64 * (2 * x.shape->R + 1) * sizeof(double), x.stream, x, s, mode); }
+static void launch_xpass(bnr_exec &x, int s, int which)
+{ BNR_LAUNCH(k_xpass, dim3(x.shape->nblk_x, 1, x.nb), dim3(256), 3 * x.shape->chunk_x * sizeof(double), x.stream, x, s, which); }
+static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
 {
-    const bnr_dev &d = c->d;
+    const bnr_dev &d = *x.shape;
     const int ntl = d.ntile * (d.ntile + 1) / 2;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
-        while (c->ev.size() < (size_t)(2 * (s + 1))) { hipEvent_t e; hipEventCreate(&e); c->ev.push_back(e); }
-        e0 = c->ev[2 * s]; e1 = c->ev[2 * s + 1];
+        while (x.ev.size() < (size_t)(2 * (s + 1))) { hipEvent_t e; hipEventCreate(&e); x.ev.push_back(e); }
+        e0 = x.ev[2 * s]; e1 = x.ev[2 * s + 1];
         hipEventRecord(e0, st);
     }
-    hipLaunchKernelGGL(k_gram, dim3(ntl * d.ksplit), dim3(1024), 0, st, c->d, s);
+    BNR_LAUNCH(k_gram, dim3(round_up(ntl * d.ksplit, 8), 1, x.nb), dim3(1024), 0, st, x, s);
     if (timed) hipEventRecord(e1, st);
-    hipLaunchKernelGGL(k_gram_reduce, dim3(ntl, 8), dim3(256), 0, st, c->d, s);
+    BNR_LAUNCH(k_gram_reduce, dim3(ntl, 8, x.nb), dim3(256), 0, st, x, s);
 }
-static void launch_rhs(bnr_chain *c, int s) { hipLaunchKernelGGL(k_rhs, dim3(c->d.n_pad / 64), dim3(256), 0, c->stream, c->d, s); }
-static void launch_chol(bnr_chain *c, int s, hipStream_t st)
+static void launch_rhs(bnr_exec &x, int s) { BNR_LAUNCH(k_rhs, dim3(x.shape->n_pad / 64, 1, x.nb), dim3(256), 0, x.stream, x, s); }
+static void launch_chol(bnr_exec &x, int s, hipStream_t st)
 {
-    const int nbk = c->d.n_pad / BNR_NB;
+    const int nbk = x.shape->n_pad / BNR_NB;
     for (int p = 0; p < nbk; ++p)
-        hipLaunchKernelGGL(k_chol_step, dim3(bnr_chol_npanel(nbk, p) + bnr_chol_ntile(nbk, p)), dim3(256), 0, st, c->d, p, s);
+        BNR_LAUNCH(k_chol_step, dim3(bnr_chol_npanel(nbk, p) + bnr_chol_ntile(nbk, p), 1, x.nb), dim3(256), 0, st, x, p, s);
 }
-static void launch_solve(bnr_chain *c)
+static void launch_solve(bnr_exec &x)
 {
-    hipLaunchKernelGGL(k_solve_w, dim3(c->d.n_pad / 4), dim3(256), 0, c->stream, c->d);
-    hipLaunchKernelGGL(k_solve_a4, dim3(c->d.n_pad / BNR_NB), dim3(1024), (c->d.n_pad + 32 * 33) * sizeof(double), c->stream, c->d);
+    BNR_LAUNCH(k_solve_w, dim3(x.shape->n_pad / 4, 1, x.nb), dim3(256), 0, x.stream, x);
+    BNR_LAUNCH(k_solve_a4, dim3(x.shape->n_pad / BNR_NB, 1, x.nb), dim3(1024), (x.shape->n_pad + 32 * 33) * sizeof(double), x.stream, x);
 }
-static void launch_backproj(bnr_chain *c, int s, int flags)
+static void launch_backproj(bnr_exec &x, int s, int flags)
 {
-    size_t lds = std::max<size_t>(c->d.n_pad + 64, (size_t)(3 * c->d.R + 1) * 33) * sizeof(double);
-    hipLaunchKernelGGL(k_backproj, dim3(c->d.nblk_bp), dim3(256), lds, c->stream, c->d, s, flags);
+    size_t lds = std::max<size_t>(x.shape->n_pad + 64, (size_t)(3 * x.shape->R + 1) * 33) * sizeof(double);
+    BNR_LAUNCH(k_backproj, dim3(x.shape->nblk_bp, 1, x.nb), dim3(256), lds, x.stream, x, s, flags);
 }
-static void launch_tail(bnr_chain *c, int s, int mask, int xg_src)
-{ hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), (size_t)c->d.R * c->d.V * sizeof(double), c->stream, c->d, s, mask, xg_src); }
-static hipEvent_t next_event(bnr_chain *c)
+static void launch_tail(bnr_exec &x, int s, int mask, int xg_src)
+{ BNR_LAUNCH(k_tail, dim3(1, 1, x.nb), dim3(1024), (size_t)x.shape->R * x.shape->V * sizeof(double), x.stream, x, s, mask, xg_src); }
+static hipEvent_t next_event(bnr_exec &x)
 {
-    if (c->fj_next >= c->fj.size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); c->fj.push_back(e); }
-    return c->fj[c->fj_next++];
+    if (x.fj_next >= x.fj.size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); x.fj.push_back(e); }
+    return x.fj[x.fj_next++];
 }
 
 // One sweep for plan slot s (gibbs_sample!, gibbs.jl:663-677).  The scalar tail of the PREVIOUS sweep (theta, Delta, M,
@@ -339,66 +422,68 @@ static hipEvent_t next_event(bnr_chain *c)
 //   branch A (stream):  tail(s-1) -> k_node(s) -> k_xpass(s) -> k_rhs(s)                 (~100 us of scalar/latency work)
 //   branch B (stream2): k_gram(s) -> k_gram_reduce -> k_chol_step x nbk                  (the factorization needs no rhs)
 //   joined:             k_solve_w -> k_solve_a4 -> k_backproj(s)
-static void launch_sweep(bnr_chain *c, int s, bool prev_tail)
+// For a lockstep group every launch covers all members (grid z): the sequential panel chain of the factorization and
+// the launch latencies are paid once per sweep of the whole group.
+static void launch_sweep(bnr_exec &x, int s, bool prev_tail)
 {
-    const bool timed = c->profiling != 0;
-    const bool overlap = c->overlap != 0;
-    hipStream_t sb = overlap ? c->stream2 : c->stream;
+    const bool timed = x.profiling != 0;
+    const bool overlap = x.overlap != 0;
+    hipStream_t sb = overlap ? x.stream2 : x.stream;
     if (overlap) {
-        hipEvent_t ef = next_event(c);
-        hipEventRecord(ef, c->stream);
-        hipStreamWaitEvent(c->stream2, ef, 0);
-        launch_gram(c, s, sb, timed);
-        launch_chol(c, s, sb);
-        hipEventRecord(next_event(c), c->stream2);
+        hipEvent_t ef = next_event(x);
+        hipEventRecord(ef, x.stream);
+        hipStreamWaitEvent(x.stream2, ef, 0);
+        launch_gram(x, s, sb, timed);
+        launch_chol(x, s, sb);
+        hipEventRecord(next_event(x), x.stream2);
     }
-    if (prev_tail) launch_tail(c, s - 1, 1023, 0);
-    launch_node(c, s, 3);
-    launch_xpass(c, s, 3);
-    launch_rhs(c, s);
-    if (overlap) hipStreamWaitEvent(c->stream, c->fj[c->fj_next - 1], 0);
-    else { launch_gram(c, s, sb, timed); launch_chol(c, s, sb); }
-    launch_solve(c);
-    launch_backproj(c, s, 7);
+    if (prev_tail) launch_tail(x, s - 1, 1023, 0);
+    launch_node(x, s, 3);
+    launch_xpass(x, s, 3);
+    launch_rhs(x, s);
+    if (overlap) hipStreamWaitEvent(x.stream, x.fj[x.fj_next - 1], 0);
+    else { launch_gram(x, s, sb, timed); launch_chol(x, s, sb); }
+    launch_solve(x);
+    launch_backproj(x, s, 7);
 }
 
 // with profiling on: after a batch, read the HIP events recorded around the k_gram launches of that batch (recorded on
 // the stream the kernel runs on)
-static int collect_gram_times(bnr_chain *c, int nsweeps)
+static int collect_gram_times(bnr_exec &x, int nsweeps)
 {
-    if (!c->profiling) return BNR_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!x.profiling) return BNR_OK;
+    HIPCHK(hipStreamSynchronize(x.stream));
     for (int s = 0; s < nsweeps; ++s) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev[2 * s], c->ev[2 * s + 1]) == hipSuccess) { c->t_gram_acc += ms; c->n_gram += 1; }
+        if (hipEventElapsedTime(&ms, x.ev[2 * s], x.ev[2 * s + 1]) == hipSuccess) { x.t_gram_acc += ms; x.n_gram += 1; }
     }
     return BNR_OK;
 }
 
-static int launch_range(bnr_chain *c, int count)
+static int launch_range(bnr_exec &x, int count)
 {
     int done = 0;
-    if (c->use_graph && !c->profiling && c->graph_k > 0) {     // profiling records HIP events around k_gram: eager launches
-        const int K = c->graph_k;
+    if (x.use_graph && !x.profiling && x.graph_k > 0) {     // profiling records HIP events around k_gram: eager launches
+        const int K = x.graph_k;
         while (count - done >= K) {
-            if (!c->gexec) {
-                c->fj_next = 0;
-                HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-                for (int s = 0; s < K; ++s) launch_sweep(c, s, true);
-                hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, c->stream, c->pbase_dev, K);
-                HIPCHK(hipStreamEndCapture(c->stream, &c->graph));
-                HIPCHK(hipGraphInstantiate(&c->gexec, c->graph, nullptr, nullptr, 0));
+            if (!x.gexec) {
+                x.fj_next = 0;
+                HIPCHK(hipStreamBeginCapture(x.stream, hipStreamCaptureModeRelaxed));
+                for (int s = 0; s < K; ++s) launch_sweep(x, s, true);
+                hipLaunchKernelGGL(k_advance, dim3(x.nb), dim3(1), 0, x.stream, (const bnr_dev *)x.cds, K);
+                HIPCHK(hipStreamEndCapture(x.stream, &x.graph));
+                HIPCHK(hipGraphInstantiate(&x.gexec, x.graph, nullptr, nullptr, 0));
             }
-            HIPCHK(hipGraphLaunch(c->gexec, c->stream));
+            HIPCHK(hipGraphLaunch(x.gexec, x.stream));
             done += K;
         }
     }
     const int r = count - done;
-    c->fj_next = 0;
-    for (int s = 0; s < r; ++s) launch_sweep(c, s, true);
+    x.fj_next = 0;
+    for (int s = 0; s < r; ++s) launch_sweep(x, s, true);
     if (r > 0) {
-        hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, c->stream, c->pbase_dev, r);
-        int rc = collect_gram_times(c, r);
+        hipLaunchKernelGGL(k_advance, dim3(x.nb), dim3(1), 0, x.stream, (const bnr_dev *)x.cds, r);
+        int rc = collect_gram_times(x, r);
         if (rc) return rc;
     }
     return BNR_OK;
@@ -410,21 +495,21 @@ static int refresh_carried(bnr_chain *c, int r)
     if (c->carried_row == r) return BNR_OK;
     int rc = ensure_plan(c, 1);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->x.stream));
     c->plan_pin[0] = bnr_plan_entry{0u, r, r, 0};
     rc = upload_plan(c, 1);
     if (rc) return rc;
-    launch_xpass(c, 0, 4);
-    launch_tail(c, 0, 64 | 256, 1);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    launch_xpass(c->x, 0, 4);
+    launch_tail(c->x, 0, 64 | 256, 1);
+    HIPCHK(hipStreamSynchronize(c->x.stream));
     c->carried_row = r;
     return check_launch("refresh");
 }
 
 static int fetch_status(bnr_chain *c)
 {
-    HIPCHK(hipMemcpyAsync(c->counters_host, c->d.counters, sizeof(long long) * 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyAsync(c->counters_host, c->d.counters, sizeof(long long) * 16, hipMemcpyDeviceToHost, c->x.stream));
+    HIPCHK(hipStreamSynchronize(c->x.stream));
     if (c->counters_host[8] > 0) return fail(BNR_ERR_HIP, "stream ordering violated: the factorization started before the Gram branch finished");
     if (c->counters_host[3] > 0) {
         char buf[160];
@@ -439,10 +524,10 @@ int bnr_chain_init_prior(bnr_chain *c)
 {
     if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
     HIPCHK(hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_init_prior, dim3(1), dim3(256), 0, c->stream, c->d);
+    hipLaunchKernelGGL(k_init_prior, dim3(1), dim3(256), 0, c->x.stream, c->d);
     int rc = check_launch("k_init_prior");
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->x.stream));
     c->iter = 1;
     c->carried_row = -1;
     c->next_row = 2;
@@ -474,9 +559,50 @@ static int enqueue_run(bnr_chain *c, int first_index, int nburn, int total, int 
     if (maxrow > c->d.tot) { c->iter -= count; return fail(BNR_ERR_BAD_ARG, "run would write past the table (tot_save too small)"); }
     rc = upload_plan(c, count + 1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_setbase, dim3(1), dim3(1), 0, c->stream, c->pbase_dev, 1);
+    hipLaunchKernelGGL(k_setbase, dim3(1), dim3(1), 0, c->x.stream, (const bnr_dev *)c->x.cds, 1);
     c->next_row = j;
     c->carried_row = -1;
+    return BNR_OK;
+}
+
+// issue `count` planned sweeps on x (a chain or a lockstep group), ticking cb every prog_freq iterations
+// (gibbs.jl:854-856), then the scalar tail of the last sweep; returns with the stream drained
+static int run_exec(bnr_exec &x, int first_index, int count, int prog_freq, bnr_progress_cb cb, void *user)
+{
+    int rc;
+    x.t_gram_acc = 0; x.n_gram = 0;
+    hipEvent_t r0 = nullptr, r1 = nullptr;
+    if (x.profiling) { hipEventCreate(&r0); hipEventCreate(&r1); hipEventRecord(r0, x.stream); }
+    if (cb && prog_freq > 0) {
+        int s = 0;
+        while (s < count) {
+            int i = first_index + s;
+            int next_tick = ((i + prog_freq - 1) / prog_freq) * prog_freq;
+            int seg = std::min(count - s, next_tick - i + 1);
+            rc = launch_range(x, seg);
+            if (rc) return rc;
+            s += seg;
+            if ((first_index + s - 1) % prog_freq == 0) {
+                HIPCHK(hipStreamSynchronize(x.stream));
+                cb(user, (int64_t)s);
+            }
+        }
+    } else {
+        rc = launch_range(x, count);
+        if (rc) return rc;
+    }
+    if (count > 0) launch_tail(x, -1, 1023, 0);                        // scalar tail of the last sweep
+    if (x.profiling) hipEventRecord(r1, x.stream);
+    rc = check_launch("sweep");
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(x.stream));
+    if (x.profiling && count > 0) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, r0, r1);
+        x.t_iter_us = 1e3 * ms / count; x.n_iter = count;
+        x.t_gram_us = x.n_gram ? 1e3 * x.t_gram_acc / x.n_gram : 0;
+        hipEventDestroy(r0); hipEventDestroy(r1);
+    }
     return BNR_OK;
 }
 
@@ -488,42 +614,106 @@ int bnr_chain_run(bnr_chain *c, int32_t first_index, int32_t nburn, int32_t tota
     int rc = enqueue_run(c, first_index, nburn, total, purge_burn);
     if (rc) return rc;
     const int count = total - first_index + 1;
-    c->t_gram_acc = 0; c->n_gram = 0;
-    hipEvent_t r0 = nullptr, r1 = nullptr;
-    if (c->profiling) { hipEventCreate(&r0); hipEventCreate(&r1); hipEventRecord(r0, c->stream); }
-    if (cb && prog_freq > 0) {
-        int s = 0;
-        while (s < count) {                                          // tick every prog_freq iterations (gibbs.jl:854-856)
-            int i = first_index + s;
-            int next_tick = ((i + prog_freq - 1) / prog_freq) * prog_freq;
-            int seg = std::min(count - s, next_tick - i + 1);
-            rc = launch_range(c, seg);
-            if (rc) return rc;
-            s += seg;
-            if ((first_index + s - 1) % prog_freq == 0) {
-                HIPCHK(hipStreamSynchronize(c->stream));
-                cb(user, (int64_t)s);
-            }
-        }
-    } else {
-        rc = launch_range(c, count);
-        if (rc) return rc;
-    }
-    if (count > 0) launch_tail(c, -1, 1023, 0);                        // scalar tail of the last sweep
-    if (c->profiling) hipEventRecord(r1, c->stream);
-    rc = check_launch("sweep");
+    rc = run_exec(c->x, first_index, count, prog_freq, cb, user);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->profiling && count > 0) {
-        float ms = 0;
-        hipEventElapsedTime(&ms, r0, r1);
-        c->t_iter_us = 1e3 * ms / count; c->n_iter = count;
-        c->t_gram_us = c->n_gram ? 1e3 * c->t_gram_acc / c->n_gram : 0;
-        hipEventDestroy(r0); hipEventDestroy(r1);
-    }
     if (count > 0) c->carried_row = c->plan_pin[count].row;
     if (next_row) *next_row = c->next_row;
     return fetch_status(c);
+}
+
+// ------------------------------------------------------------------------------------------ lockstep groups
+// Several equally shaped chains on one GPU advance together: every kernel of a sweep is launched once for the whole
+// group (blockIdx.z = member).  Chains stay independent (own seed, own trace, gibbs.jl:928); results are bitwise those of
+// running each chain alone.  What the group buys: the launch latencies and the sequential panel chain of the n x n
+// factorization (the critical path of ONE chain) are paid once per sweep of all members, and the Gram kernels of the
+// members fill the chip back to back.
+int bnr_group_create(bnr_chain *const *chains, int32_t nchains, bnr_group **out)
+{
+    if (!chains || !out || nchains < 1 || nchains > 1024) return fail(BNR_ERR_BAD_ARG, "need 1 <= nchains <= 1024");
+    for (int i = 0; i < nchains; ++i) {
+        bnr_chain *c = chains[i];
+        if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain in group");
+        if (c->group) return fail(BNR_ERR_BAD_ARG, "chain already belongs to a group");
+        if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");
+        for (int k = 0; k < i; ++k) if (chains[k] == c) return fail(BNR_ERR_BAD_ARG, "chain listed twice");
+        const bnr_dev &a = chains[0]->d, &b = c->d;
+        if (c->device != chains[0]->device || a.n != b.n || a.V != b.V || a.R != b.R)
+            return fail(BNR_ERR_BAD_ARG, "chains of a group must live on one device and have equal n, V, R");
+    }
+    HIPCHK(hipSetDevice(chains[0]->device));
+    bnr_group *g = new bnr_group();
+    g->m.assign(chains, chains + nchains);
+    int rc = exec_init(g->x, chains[0]->device, nchains, &chains[0]->d);
+    if (rc) { exec_free(g->x); delete g; return rc; }
+    for (bnr_chain *c : g->m) c->group = g;
+    *out = g;
+    return BNR_OK;
+}
+
+int bnr_group_destroy(bnr_group *g)
+{
+    if (!g) return BNR_OK;
+    hipSetDevice(g->x.device);
+    for (bnr_chain *c : g->m) c->group = nullptr;
+    exec_free(g->x);
+    delete g;
+    return BNR_OK;
+}
+
+int bnr_group_run(bnr_group *g, int32_t first_index, int32_t nburn, int32_t total, int32_t purge_burn,
+                  int32_t prog_freq, bnr_progress_cb cb, void *user, int32_t *next_row)
+{
+    if (!g) return fail(BNR_ERR_BAD_ARG, "NULL group");
+    HIPCHK(hipSetDevice(g->x.device));
+    for (bnr_chain *c : g->m) {
+        if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending on a member");
+        if (c->d.tot != g->m[0]->d.tot) return fail(BNR_ERR_BAD_ARG, "members of a group must have tables of equal length");
+    }
+    if (first_index < 2 || total < first_index - 1) return fail(BNR_ERR_BAD_ARG, "need first_index>=2 and total>=first_index-1");
+    const int count = total - first_index + 1;
+    int rc;
+    for (bnr_chain *c : g->m) {
+        rc = enqueue_run(c, first_index, nburn, total, purge_burn);     // every member walks the same (i, j) schedule
+        if (rc) return rc;
+    }
+    std::vector<bnr_dev> host;
+    for (bnr_chain *c : g->m) { HIPCHK(hipStreamSynchronize(c->x.stream)); host.push_back(c->d); }
+    HIPCHK(hipMemcpy(g->x.cds, host.data(), sizeof(bnr_dev) * host.size(), hipMemcpyHostToDevice));
+    rc = run_exec(g->x, first_index, count, prog_freq, cb, user);
+    if (rc) return rc;
+    for (bnr_chain *c : g->m) {
+        if (count > 0) c->carried_row = c->plan_pin[count].row;
+        int r2 = fetch_status(c);
+        if (r2 && !rc) rc = r2;
+    }
+    if (next_row) *next_row = g->m[0]->next_row;
+    return rc;
+}
+
+static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
+{
+    if (!strcmp(name, "graph")) { x.use_graph = (int)value; return BNR_OK; }
+    if (!strcmp(name, "overlap")) { x.overlap = (int)value; drop_graph(x); return BNR_OK; }
+    if (!strcmp(name, "graph_k")) { if (value < 1 || value > 256) return fail(BNR_ERR_BAD_ARG, "graph_k out of range"); x.graph_k = (int)value; drop_graph(x); return BNR_OK; }
+    if (!strcmp(name, "profiling")) { if (x.profiling != (int)value) drop_graph(x); x.profiling = (int)value; return BNR_OK; }
+    return fail(BNR_ERR_BAD_ARG, std::string("unknown option ") + name);
+}
+static int exec_last_timing(bnr_exec &x, int which, double *avg_us, int64_t *launches)
+{
+    if (which == 0) { *avg_us = x.t_iter_us; if (launches) *launches = x.n_iter; }
+    else if (which == 1) { *avg_us = x.t_gram_us; if (launches) *launches = x.n_gram; }
+    else return fail(BNR_ERR_BAD_ARG, "which must be 0 or 1");
+    return BNR_OK;
+}
+int bnr_group_set_option(bnr_group *g, const char *name, int64_t value)
+{
+    if (!g || !name) return fail(BNR_ERR_BAD_ARG, "NULL argument");
+    return exec_set_option(g->x, name, value);
+}
+int bnr_group_last_timing(bnr_group *g, int32_t which, double *avg_us, int64_t *launches)
+{
+    if (!g || !avg_us) return fail(BNR_ERR_BAD_ARG, "NULL argument");
+    return exec_last_timing(g->x, which, avg_us, launches);
 }
 
 int bnr_chain_run_async(bnr_chain *c, int32_t first_index, int32_t nburn, int32_t total, int32_t purge_burn)
@@ -533,11 +723,11 @@ int bnr_chain_run_async(bnr_chain *c, int32_t first_index, int32_t nburn, int32_
     int rc = enqueue_run(c, first_index, nburn, total, purge_burn);
     if (rc) return rc;
     const int count = total - first_index + 1;
-    int saved = c->profiling;
-    c->profiling = 0;
-    rc = launch_range(c, count);
-    if (!rc && count > 0) launch_tail(c, -1, 1023, 0);
-    c->profiling = saved;
+    int saved = c->x.profiling;
+    c->x.profiling = 0;
+    rc = launch_range(c->x, count);
+    if (!rc && count > 0) launch_tail(c->x, -1, 1023, 0);
+    c->x.profiling = saved;
     if (rc) return rc;
     c->pending = true;
     if (count > 0) c->carried_row = -2 - c->plan_pin[count].row;        // becomes valid at sync
@@ -548,7 +738,7 @@ int bnr_chain_sync(bnr_chain *c, int32_t *next_row)
 {
     if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->x.stream));
     if (c->pending) {
         c->pending = false;
         if (c->carried_row <= -2) c->carried_row = -2 - c->carried_row;
@@ -565,7 +755,7 @@ static int hook_begin(bnr_chain *c, int row, int64_t iter, bool need_carried)
     if (row < 2 || row > c->d.tot) return fail(BNR_ERR_BAD_ARG, "row out of range (need 2 <= row <= tot_save)");
     HIPCHK(hipSetDevice(c->device));
     if (need_carried) { int rc = refresh_carried(c, row - 2); if (rc) return rc; }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->x.stream));
     c->plan_pin[0] = bnr_plan_entry{(uint32_t)iter, row - 1, row - 2, 0};
     return upload_plan(c, 1);
 }
@@ -581,8 +771,8 @@ int bnr_gibbs_step(bnr_chain *c, int32_t row, int64_t iter)
 {
     int rc = hook_begin(c, row, iter, true);
     if (rc) return rc;
-    launch_sweep(c, 0, false);
-    launch_tail(c, 0, 1023, 0);
+    launch_sweep(c->x, 0, false);
+    launch_tail(c->x, 0, 1023, 0);
     rc = hook_end(c, "gibbs_step");
     if (!rc) { c->carried_row = row - 1; c->iter = iter; }
     return rc;
@@ -591,82 +781,82 @@ int bnr_update_tau2(bnr_chain *c, int32_t row, int64_t iter)
 {
     int rc = hook_begin(c, row, iter, true);
     if (rc) return rc;
-    launch_node(c, 0, 1);
+    launch_node(c->x, 0, 1);
     return hook_end(c, "update_tau2");
 }
 int bnr_update_u_xi(bnr_chain *c, int32_t row, int64_t iter)
 {
     int rc = hook_begin(c, row, iter, false);
     if (rc) return rc;
-    launch_node(c, 0, 2 | 4);
+    launch_node(c->x, 0, 2 | 4);
     return hook_end(c, "update_u_xi");
 }
 int bnr_update_gamma(bnr_chain *c, int32_t row, int64_t iter)
 {
     int rc = hook_begin(c, row, iter, false);
     if (rc) return rc;
-    launch_node(c, 0, 0);            // publishes tau = sqrt(tau2[row])
-    launch_xpass(c, 0, 3);
-    launch_gram(c, 0, c->stream, false);
-    launch_rhs(c, 0);
-    launch_chol(c, 0, c->stream);
-    launch_solve(c);
-    launch_backproj(c, 0, 1);
+    launch_node(c->x, 0, 0);            // publishes tau = sqrt(tau2[row])
+    launch_xpass(c->x, 0, 3);
+    launch_gram(c->x, 0, c->x.stream, false);
+    launch_rhs(c->x, 0);
+    launch_chol(c->x, 0, c->x.stream);
+    launch_solve(c->x);
+    launch_backproj(c->x, 0, 1);
     return hook_end(c, "update_gamma");
 }
 int bnr_update_D(bnr_chain *c, int32_t row, int64_t iter)
 {
     int rc = hook_begin(c, row, iter, false);
     if (rc) return rc;
-    launch_xpass(c, 0, 1);
-    launch_backproj(c, 0, 2);
+    launch_xpass(c->x, 0, 1);
+    launch_backproj(c->x, 0, 2);
     return hook_end(c, "update_D");
 }
 int bnr_update_theta(bnr_chain *c, int32_t row, int64_t iter)
 {
     int rc = hook_begin(c, row, iter, false);
     if (rc) return rc;
-    launch_xpass(c, 0, 1);
-    launch_backproj(c, 0, 4);
-    launch_tail(c, 0, 1, 0);
+    launch_xpass(c->x, 0, 1);
+    launch_backproj(c->x, 0, 4);
+    launch_tail(c->x, 0, 1, 0);
     return hook_end(c, "update_theta");
 }
 int bnr_update_Delta(bnr_chain *c, int32_t row, int64_t iter)
 {
     int rc = hook_begin(c, row, iter, false);
     if (rc) return rc;
-    launch_tail(c, 0, 2, 0);
+    launch_tail(c->x, 0, 2, 0);
     return hook_end(c, "update_Delta");
 }
 int bnr_update_M(bnr_chain *c, int32_t row, int64_t iter)
 {
     int rc = hook_begin(c, row, iter, false);
     if (rc) return rc;
-    launch_tail(c, 0, 4, 0);
+    launch_tail(c->x, 0, 4, 0);
     return hook_end(c, "update_M");
 }
 int bnr_update_mu(bnr_chain *c, int32_t row, int64_t iter)
 {
     int rc = hook_begin(c, row, iter, false);
     if (rc) return rc;
-    launch_xpass(c, 0, 4);
-    launch_tail(c, 0, 8, 1);
+    launch_xpass(c->x, 0, 4);
+    launch_tail(c->x, 0, 8, 1);
     return hook_end(c, "update_mu");
 }
 int bnr_update_Lambda(bnr_chain *c, int32_t row, int64_t iter)
 {
     int rc = hook_begin(c, row, iter, false);
     if (rc) return rc;
-    launch_xpass(c, 0, 1);
-    launch_backproj(c, 0, 4);
-    launch_tail(c, 0, 16, 0);
+    launch_xpass(c->x, 0, 1);
+    launch_backproj(c->x, 0, 4);
+    launch_tail(c->x, 0, 16, 0);
     return hook_end(c, "update_Lambda");
 }
 int bnr_update_pi(bnr_chain *c, int32_t row, int64_t iter)
 {
     int rc = hook_begin(c, row, iter, false);
     if (rc) return rc;
-    launch_tail(c, 0, 32, 0);
+    launch_tail(c->x, 0, 32, 0);
     return hook_end(c, "update_pi");
 }
 
@@ -718,16 +908,16 @@ static int table_io(bnr_chain *c, bool fetch, int first_row, int last_row, int h
             double *hbase = cols[k] + (size_t)(first_row - 1 + host_off) + (size_t)host_tot * c0;
             hipError_t e;
             if (fetch) {
-                hipLaunchKernelGGL(k_fetch_cols, grid, block, 0, c->stream, (const double *)d.trace, d.rowlen, cdsc[k].off + c0, nc, first_row - 1, nrows, stage);
+                hipLaunchKernelGGL(k_fetch_cols, grid, block, 0, c->x.stream, (const double *)d.trace, d.rowlen, cdsc[k].off + c0, nc, first_row - 1, nrows, stage);
                 e = hipMemcpy2DAsync(hbase, (size_t)host_tot * sizeof(double), stage, (size_t)nrows * sizeof(double),
-                                     (size_t)nrows * sizeof(double), nc, hipMemcpyDeviceToHost, c->stream);
+                                     (size_t)nrows * sizeof(double), nc, hipMemcpyDeviceToHost, c->x.stream);
             } else {
                 e = hipMemcpy2DAsync(stage, (size_t)nrows * sizeof(double), hbase, (size_t)host_tot * sizeof(double),
-                                     (size_t)nrows * sizeof(double), nc, hipMemcpyHostToDevice, c->stream);
-                hipLaunchKernelGGL(k_load_cols, grid, block, 0, c->stream, d.trace, d.rowlen, cdsc[k].off + c0, nc, first_row - 1, nrows, (const double *)stage);
+                                     (size_t)nrows * sizeof(double), nc, hipMemcpyHostToDevice, c->x.stream);
+                hipLaunchKernelGGL(k_load_cols, grid, block, 0, c->x.stream, d.trace, d.rowlen, cdsc[k].off + c0, nc, first_row - 1, nrows, (const double *)stage);
             }
             if (e != hipSuccess) rc = fail(BNR_ERR_HIP, std::string("table copy: ") + hipGetErrorString(e));
-            if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(BNR_ERR_HIP, "table copy sync failed");
+            if (!rc && hipStreamSynchronize(c->x.stream) != hipSuccess) rc = fail(BNR_ERR_HIP, "table copy sync failed");
         }
     }
     hipFree(stage);
@@ -765,8 +955,8 @@ int bnr_chain_move_rows(bnr_chain *c, int32_t to_row, int32_t from_row, int32_t 
     // the reference copies row by row in increasing i (gibbs.jl:991-993): emulate exactly, also when ranges overlap
     for (int i = 0; i < count; ++i)
         HIPCHK(hipMemcpyAsync(d.trace + (size_t)(to_row - 1 + i) * d.rowlen, d.trace + (size_t)(from_row - 1 + i) * d.rowlen, rb,
-                              hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+                              hipMemcpyDeviceToDevice, c->x.stream));
+    HIPCHK(hipStreamSynchronize(c->x.stream));
     c->carried_row = -1;
     return BNR_OK;
 }
@@ -777,7 +967,7 @@ int bnr_chain_resize(bnr_chain *c, int32_t new_tot)
     if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");
     if (new_tot < 2) return fail(BNR_ERR_BAD_ARG, "new_tot must be >= 2");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->x.stream));
     bnr_dev &d = c->d;
     double *old = d.trace, *nt = nullptr;
     int rc = alloc_trace(c, new_tot, &nt);
@@ -786,8 +976,8 @@ int bnr_chain_resize(bnr_chain *c, int32_t new_tot)
     HIPCHK(hipMemcpy(nt, old, keep, hipMemcpyDeviceToDevice));
     hipFree(old);
     d.trace = nt; d.tot = new_tot;
-    drop_graph(c);
-    return BNR_OK;
+    drop_graph(c->x);
+    return sync_dev(c);
 }
 
 // ------------------------------------------------------------------------------------------ Rhat
@@ -801,9 +991,9 @@ int bnr_chain_rhat_stats(bnr_chain *c, int32_t first_row, int32_t nsamp, double 
     const int np = d.q + d.V;
     double *out = nullptr;
     HIPCHK(hipMalloc((void **)&out, sizeof(double) * 4 * np));
-    hipLaunchKernelGGL(k_rhat_stats, dim3((np + 127) / 128), dim3(128), 0, c->stream, c->d, first_row - 1, nsamp, out);
-    hipError_t e = hipMemcpyAsync(stats, out, sizeof(double) * 4 * np, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipLaunchKernelGGL(k_rhat_stats, dim3((np + 127) / 128), dim3(128), 0, c->x.stream, c->d, first_row - 1, nsamp, out);
+    hipError_t e = hipMemcpyAsync(stats, out, sizeof(double) * 4 * np, hipMemcpyDeviceToHost, c->x.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->x.stream);
     hipFree(out);
     if (e != hipSuccess) return fail(BNR_ERR_HIP, std::string("rhat_stats: ") + hipGetErrorString(e));
     return check_launch("k_rhat_stats");
@@ -859,7 +1049,7 @@ int bnr_chain_debug_copy(bnr_chain *c, int32_t which, double *out, int64_t count
 {
     if (!c || !out) return fail(BNR_ERR_BAD_ARG, "bad argument");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->x.stream));
     const double *src = which == 0 ? c->d.E : (which == 1 ? c->d.bw : (which == 2 ? c->d.a4 : c->d.Gpart));
     HIPCHK(hipMemcpy(out, src, sizeof(double) * count, hipMemcpyDeviceToHost));
     return BNR_OK;
@@ -871,7 +1061,7 @@ int bnr_chain_debug_time_gram(bnr_chain *c, int32_t reps, double *avg_us)
     int gridsz = 0;
     if (reps >= 1000000) { gridsz = reps / 1000000; reps = reps % 1000000; }
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->x.stream));
     c->plan_pin[0] = bnr_plan_entry{1u, 1, 0, 0};
     int rc = upload_plan(c, 1);
     if (rc) return rc;
@@ -879,11 +1069,11 @@ int bnr_chain_debug_time_gram(bnr_chain *c, int32_t reps, double *avg_us)
     const int ntl = d.ntile * (d.ntile + 1) / 2;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k_gram, dim3(ntl * d.ksplit), dim3(1024), 0, c->stream, c->d, 0);
-    hipEventRecord(e0, c->stream);
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_gram, dim3(gridsz ? gridsz : ntl * d.ksplit), dim3(1024), 0, c->stream, c->d, 0);
-    hipEventRecord(e1, c->stream);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one>), dim3(round_up(ntl * d.ksplit, 8)), dim3(1024), 0, c->x.stream, bnr_one{c->d}, 0);
+    hipEventRecord(e0, c->x.stream);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one>), dim3(gridsz ? gridsz : round_up(ntl * d.ksplit, 8)), dim3(1024), 0, c->x.stream, bnr_one{c->d}, 0);
+    hipEventRecord(e1, c->x.stream);
+    HIPCHK(hipStreamSynchronize(c->x.stream));
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     hipEventDestroy(e0); hipEventDestroy(e1);
@@ -895,26 +1085,18 @@ int bnr_chain_debug_time_gram(bnr_chain *c, int32_t reps, double *avg_us)
 int bnr_chain_set_profiling(bnr_chain *c, int32_t enable)
 {
     if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
-    if (c->profiling != enable) drop_graph(c);       // the event-record nodes are part of the captured graph
-    c->profiling = enable;
-    return BNR_OK;
+    return exec_set_option(c->x, "profiling", enable);
 }
 int bnr_chain_last_timing(bnr_chain *c, int32_t which, double *avg_us, int64_t *launches)
 {
     if (!c || !avg_us) return fail(BNR_ERR_BAD_ARG, "NULL argument");
-    if (which == 0) { *avg_us = c->t_iter_us; if (launches) *launches = c->n_iter; }
-    else if (which == 1) { *avg_us = c->t_gram_us; if (launches) *launches = c->n_gram; }
-    else return fail(BNR_ERR_BAD_ARG, "which must be 0 or 1");
-    return BNR_OK;
+    return exec_last_timing(c->x, which, avg_us, launches);
 }
 
 int bnr_chain_set_option(bnr_chain *c, const char *name, int64_t value)
 {
     if (!c || !name) return fail(BNR_ERR_BAD_ARG, "NULL argument");
-    if (!strcmp(name, "graph")) { c->use_graph = (int)value; return BNR_OK; }
-    if (!strcmp(name, "overlap")) { c->overlap = (int)value; drop_graph(c); return BNR_OK; }
-    if (!strcmp(name, "graph_k")) { if (value < 1 || value > 256) return fail(BNR_ERR_BAD_ARG, "graph_k out of range"); c->graph_k = (int)value; drop_graph(c); return BNR_OK; }
-    return fail(BNR_ERR_BAD_ARG, std::string("unknown option ") + name);
+    return exec_set_option(c->x, name, value);
 }
 
 }  // extern "C"

@@ -58,6 +58,12 @@ struct bnr_dev {
     unsigned int *stamp;         // one word per k_gram_reduce workgroup: iteration id of the Gram it finished (checked by k_chol_step)
 };
 
+// How a sweep kernel finds its chain.  One chain: the struct travels by value in the kernel arguments (no dependent
+// load in front of the first useful one -- the sweep of a single chain is a latency chain of ~30 launches).  Lockstep
+// group: a device array indexed by blockIdx.z (one more scalar load, paid once per launch for all members).
+struct bnr_one { bnr_dev d; __device__ __forceinline__ const bnr_dev &get() const { return d; } };
+struct bnr_many { const bnr_dev *p; __device__ __forceinline__ const bnr_dev &get() const { return p[blockIdx.z]; } };
+
 enum { ROW_TAU2 = 0, ROW_THETA = 1, ROW_DELTA = 2, ROW_MU = 3 };
 enum { SC_RR = 0, SC_SIGQ = 1, SC_TAU = 2, SC_TAU2N = 3, SC_TAU2N_IT = 4 };   // TAU2N: tau2 pre-drawn by k_tail for iteration id TAU2N_IT
 
@@ -181,8 +187,10 @@ __device__ __forceinline__ double edge_W(const double *u, const double *lam, int
 // The V-1 other nodes are staged through LDS in chunks of 64 (one per lane: U_a = u_a .* lambda, V_a = U_a / h_a,
 // g_a / h_a), then lane p accumulates the p-th of the R(R+1)/2 + R sums sequentially over a (the reference's order).
 #define BNR_NODE_MAXSUM 9      // ceil((32*33/2 + 32) / 64)
-__global__ __launch_bounds__(64) void k_node(bnr_dev cd, int s, int mode)
+template <class SRC>
+__global__ __launch_bounds__(64) void k_node(const SRC chain_src, int s, int mode)
 {
+    const bnr_dev &cd = chain_src.get();
     extern __shared__ double shn[];                           // 64 x (2R + 1): per staged node [U(R) | V(R) | g/h]
     __shared__ double sM[BNR_RMAX * BNR_RMAX], sMinv[BNR_RMAX * BNR_RMAX], sS[BNR_RMAX * BNR_RMAX], sL[BNR_RMAX * BNR_RMAX];
     __shared__ double slam[BNR_RMAX], sc[BNR_RMAX];
@@ -335,8 +343,10 @@ __global__ __launch_bounds__(64) void k_node(bnr_dev cd, int s, int mode)
 //   sz_e = sqrt(S_prev,e) * z1_e   (Delta_gamma1 = tau * sz)   (gibbs.jl:429)           -> sz
 //   PW[b][i] = sum_{e in chunk} X[i,e] W_e ;  PA[b][i] = sum X[i,e] sz_e                 (gibbs.jl:432-433)
 // which: bit0 -> W/PW, bit1 -> sz/PA, bit2 -> PG = partial X*gamma(row `P.prev` if bit3 else row P.row)
-__global__ __launch_bounds__(256) void k_xpass(bnr_dev cd, int s, int which)
+template <class SRC>
+__global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int which)
 {
+    const bnr_dev &cd = chain_src.get();
     extern __shared__ double sh[];
     double *sW = sh, *sZ = sh + cd.chunk_x, *sG = sh + 2 * cd.chunk_x;
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
@@ -395,8 +405,10 @@ typedef double bnr_d2 __attribute__((ext_vector_type(2)));
 // LDS-staged, double-buffered K loop.  Per K-group (4 waves = 256 threads) and batch: the j-side panel X[j-rows, 8 cols]
 // and the S-scaled i-side panel are loaded one batch ahead with coalesced 16-byte global loads (registers), written to
 // LDS [col][row] with a padded column stride, and read back as MFMA fragments with ds_read_b64.
-__global__ __launch_bounds__(1024) void k_gram(bnr_dev cd, int s)
+template <class SRC>
+__global__ __launch_bounds__(1024) void k_gram(const SRC chain_src, int s)
 {
+    const bnr_dev &cd = chain_src.get();
     __shared__ double sred[BNR_GRAM_KG * BNR_GT * BNR_GT];     // 128 KiB: staging buffers during the loop, then the K-group reduction
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     const double *Sp = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
@@ -411,6 +423,8 @@ __global__ __launch_bounds__(1024) void k_gram(bnr_dev cd, int s)
 #ifdef BNR_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < 256) { cd.dbg[512 + blockIdx.x] = __builtin_amdgcn_s_memrealtime(); unsigned xcc = __builtin_amdgcn_s_getreg((20 | (0 << 6) | (3 << 11))); unsigned hwid = __builtin_amdgcn_s_getreg((4 | (0 << 6) | (31 << 11))); cd.dbg[256 + blockIdx.x] = ((unsigned long long)xcc << 32) | hwid; }
 #endif
+    // the grid's x extent is padded to a multiple of 8 so that blockIdx.x % 8 labels the XCD for every member of a group
+    if ((int)blockIdx.x >= cd.ksplit * (cd.ntile * (cd.ntile + 1) / 2)) return;
     const int task = cd.gmap[blockIdx.x];
     int t = task & 0xFFFF, ti = 0;
     const int ks = task >> 16;
@@ -516,8 +530,10 @@ __global__ __launch_bounds__(1024) void k_gram(bnr_dev cd, int s)
 // k_gram_reduce: G = sum_ks partial + I into the lower tiles of E, and Y = I.  grid = (lower tiles, 4), 256 threads.
 __host__ __device__ inline int bnr_ldE(int n_pad) { return 2 * n_pad + BNR_NB; }
 
-__global__ __launch_bounds__(256) void k_gram_reduce(bnr_dev cd, int s)
+template <class SRC>
+__global__ __launch_bounds__(256) void k_gram_reduce(const SRC chain_src, int s)
 {
+    const bnr_dev &cd = chain_src.get();
     // grid = (lower tiles, 8): each workgroup sums 512 elements (one 16-byte pair per thread) of one tile over the K slices
     int t = blockIdx.x, ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
@@ -704,8 +720,10 @@ __device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &
     __syncthreads();
     return bad;
 }
-__global__ __launch_bounds__(256, 1) void k_chol_step(bnr_dev cd, int p, int s)
+template <class SRC>
+__global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p, int s)
 {
+    const bnr_dev &cd = chain_src.get();
     __shared__ bnr_panel_lds sh;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nbk = cd.n_pad / BNR_NB;
     const size_t ld = bnr_ldE(cd.n_pad);
@@ -788,8 +806,10 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(bnr_dev cd, int p, int s)
 // Right-hand side: finishes the GEMVs of k_xpass and forms b = a1 - a3 (gibbs.jl:432-434):
 //   a1 = (y - X W - mu_prev)/tau, a3 = X sz + z2  (note (X/tau) Delta_gamma1 = X sz).
 // grid = n_pad/64 blocks of 256 threads: 64 rows x 4 partial groups; fixed summation order (deterministic).
-__global__ __launch_bounds__(256) void k_rhs(bnr_dev cd, int s)
+template <class SRC>
+__global__ __launch_bounds__(256) void k_rhs(const SRC chain_src, int s)
 {
+    const bnr_dev &cd = chain_src.get();
     __shared__ double sw[4][64], sa[4][64];
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     const double *prev = cd.trace + (size_t)P.prev * cd.rowlen;
@@ -823,8 +843,10 @@ __global__ __launch_bounds__(256) void k_rhs(bnr_dev cd, int s)
 // The factorization itself never sees b, so the scalar branch of the sweep (tail, node, X W pass, k_rhs) only has to be
 // finished here, not before the Cholesky.
 // k_solve_w: w_c = sum_{r <= c} Y[r,c] b_r  -- one wavefront per column c (contiguous).  grid = n_pad/4 blocks of 256.
-__global__ __launch_bounds__(256) void k_solve_w(bnr_dev cd)
+template <class SRC>
+__global__ __launch_bounds__(256) void k_solve_w(const SRC chain_src)
 {
+    const bnr_dev &cd = chain_src.get();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, np = cd.n_pad;
     const int c = blockIdx.x * 4 + wave;
     const size_t ld = bnr_ldE(np);
@@ -837,8 +859,10 @@ __global__ __launch_bounds__(256) void k_solve_w(bnr_dev cd)
 }
 // k_solve_a4: a4_r = sum_{c >= block(r)} Y[r,c] w_c, then X gamma_new = X W + tau X sz + tau G a4, G a4 = b - a4
 // (no third pass over X).  grid = nbk blocks (one per block row), 1024 threads = 32 rows x 32 column groups.
-__global__ __launch_bounds__(1024) void k_solve_a4(bnr_dev cd)
+template <class SRC>
+__global__ __launch_bounds__(1024) void k_solve_a4(const SRC chain_src)
 {
+    const bnr_dev &cd = chain_src.get();
     extern __shared__ double shs[];                         // n_pad (w) + 32*33 partials
     double *swv = shs, *spart = shs + cd.n_pad;
     const int np = cd.n_pad, tid = threadIdx.x;
@@ -872,8 +896,10 @@ __global__ __launch_bounds__(1024) void k_solve_a4(bnr_dev cd)
 //   S_e ~ GIG(1/2, chi = (gamma_e - W_e)^2 / tau2, psi = theta_prev)         (gibbs.jl:454-458, gig.jl)
 //   Psum[b][0] = sum_e S_e ; Psum[b][1+3r+c] = sum_e logpdf(Normal(W_c,e, sqrt(tau2 S_e)), gamma_e)  (gibbs.jl:603-605)
 // Back-projection x_e' a4: one wavefront per column, two columns in flight, a4 in LDS, DPP wave reduction.
-__global__ __launch_bounds__(256) void k_backproj(bnr_dev cd, int s, int flags)
+template <class SRC>
+__global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, int flags)
 {
+    const bnr_dev &cd = chain_src.get();
     extern __shared__ double sh[];          // n_pad (a4) + 64 (dots)
     double *sa = sh, *sdot = sh + cd.n_pad;
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
@@ -1004,8 +1030,10 @@ __device__ inline void wave_tri_inverse(const double *A, double *T, int R, int l
     bnr_wsync();
 }
 
-__global__ __launch_bounds__(1024) void k_tail(bnr_dev cd, int s, int mask, int xg_src)
+template <class SRC>
+__global__ __launch_bounds__(1024) void k_tail(const SRC chain_src, int s, int mask, int xg_src)
 {
+    const bnr_dev &cd = chain_src.get();
     extern __shared__ double su[];               // R x V: u of this row (staged once, used by Psi and by the q pass)
     __shared__ double sred[3 * 16];
     __shared__ double sPsi[BNR_RMAX * BNR_RMAX], sA[BNR_RMAX * BNR_RMAX], sT[BNR_RMAX * BNR_RMAX], sBm[BNR_RMAX * BNR_RMAX];
@@ -1238,9 +1266,9 @@ __global__ __launch_bounds__(1024) void k_tail(bnr_dev cd, int s, int mask, int 
 }
 
 // advances the plan base after a batch of sweeps (last node of the captured graph)
-__global__ void k_advance(int *pbase, int by) { if (threadIdx.x == 0 && blockIdx.x == 0) pbase[0] += by; }
+__global__ void k_advance(const bnr_dev *cds, int by) { if (threadIdx.x == 0) ((int *)cds[blockIdx.x].pbase)[0] += by; }   // grid = chains
 __global__ void k_stamp(unsigned long long *dbg, int slot) { if (threadIdx.x == 0) dbg[slot] = __builtin_amdgcn_s_memrealtime(); }
-__global__ void k_setbase(int *pbase, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) pbase[0] = v; }
+__global__ void k_setbase(const bnr_dev *cds, int v) { if (threadIdx.x == 0) ((int *)cds[blockIdx.x].pbase)[0] = v; }
 
 // ===================================================================================== k_init_prior
 // initialize_variables! (gibbs.jl:191-224) into row 0.  One block of 256 threads.

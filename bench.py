@@ -79,22 +79,18 @@ def main():
     chains = []
     for lc in range(C):
         cid = rank * C + lc + 1                                   # chain c uses stream seed + c (gibbs.jl:928)
-        ch = bnr_amd.Chain(X, y, R, tot, a.seed, cid, device=local_rank)
-        if C > 1:
-            ch.set_option("overlap", 0)       # chains overlap each other across streams; see api.ChainSet
+        ch = bnr_amd.Chain(X, y, R, tot, a.seed, cid, device=local_rank) if not chains else bnr_amd.Chain.like(chains[0], a.seed, cid, tot)
         ch.init_prior()
         chains.append(ch)
+    # several chains on one GPU advance in lockstep: one launch per kernel of a sweep covers all of them
+    runner = bnr_amd.Group(chains) if C > 1 else chains[0]
 
     def run_all(first, last, profile=False):
         if profile:
-            chains[0].set_profiling(True)
-        for ch in chains[1:]:
-            ch.run_async(first, last, last)
-        chains[0].run(first, last, last)
-        for ch in chains[1:]:
-            ch.sync()
+            runner.set_profiling(True)
+        runner.run(first, last, last)
         if profile:
-            chains[0].set_profiling(False)
+            runner.set_profiling(False)
 
     P = min(K, 200)                                  # sweeps of the HIP-event pass around k_gram (after the timed region)
 
@@ -119,7 +115,7 @@ def main():
     # kernel-duration pass: the same sweeps continue, launched eagerly with HIP events recorded around every k_gram launch
     # on the stream it runs on (the timed region above replays captured graphs, where events cannot be read back)
     run_all(W + K + 2, W + K + P + 1, profile=True)
-    gram_us, gram_n = chains[0].last_timing(1)
+    gram_us, gram_n = runner.last_timing(1)
     counters = chains[0].counters()
 
     # convergence check over all chains of the job: RCCL all-gather of the per-chain split-Rhat messages
@@ -134,11 +130,12 @@ def main():
     if rank == 0:
         total_chains = world * C
         value = total_chains * K / dt
-        flops_gram = float(n) * n * q                             # algorithmic: symmetric X diag(S) X' 
+        flops_gram = float(n) * n * q * C                         # algorithmic: symmetric X diag(S) X'  per chain of the launch
         traffic = None                                            # HBM bytes per k_gram launch from the PMC passes (tools/pmc_gram2.sh)
         pmc_file = os.path.join(ROOT, "profiles", "round1_gram_pmc.json")
         if a.config == "cfg3" and os.path.exists(pmc_file):
             traffic = json.load(open(pmc_file)).get("traffic_bytes_per_launch")
+            traffic = traffic * C if traffic is not None else None   # measured on a one-chain launch; a group launch does C times the work
         achieved = flops_gram / (gram_us * 1e-6) / 1e12 if gram_us > 0 else 0.0
         out = {
             "metric": "Gibbs iterations/sec (all chains)", "value": value, "unit": "iterations/s",
@@ -157,6 +154,8 @@ def main():
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X, y, R, a.seed)
         print(json.dumps(out))
+    if C > 1:
+        runner.close()
     for ch in chains:
         ch.close()
     if dist:

@@ -58,6 +58,11 @@ int bnr_device_count(int *count);
  * The RNG stream is keyed by seed + chain_id (the reference's Xoshiro(seed+c), gibbs.jl:928). */
 int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const double *y, const bnr_hyper *hyper,
                      uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save, bnr_chain **out);
+/* Another chain of the same fit on the same device: same X, y, sizes and hyper-parameters as `donor`, own seed /
+ * chain id, own table and work space.  The read-only device inputs (X, y, index maps) are SHARED with the donor, not
+ * copied -- the reference hands the same X, y to every pmap worker (gibbs.jl:946-948) -- and live until the last chain
+ * using them is destroyed. */
+int bnr_chain_create_like(const bnr_chain *donor, uint64_t seed, int32_t chain_id, int32_t tot_save, bnr_chain **out);
 int bnr_chain_destroy(bnr_chain *chain);
 
 /* initialize_variables! (gibbs.jl:191-224): draws row 1 from the priors; sets the iteration counter to 1. */
@@ -72,6 +77,22 @@ int bnr_chain_run(bnr_chain *chain, int32_t first_index, int32_t nburn, int32_t 
  * that share one GPU overlap (the reference runs chains concurrently under pmap, gibbs.jl:946). */
 int bnr_chain_run_async(bnr_chain *chain, int32_t first_index, int32_t nburn, int32_t total, int32_t purge_burn);
 int bnr_chain_sync(bnr_chain *chain, int32_t *next_row);
+
+/* Lockstep group: the chains one `pmap` call of generate_samples! hands to the workers (gibbs.jl:946-948, 989-1000)
+ * when several of them live on ONE GPU.  All members (equal n, V, R and table length, same device) advance together:
+ * bnr_group_run is run! (gibbs.jl:849-864) for every member with the same (first_index, nburn, total, purge_burn),
+ * each kernel of a sweep being launched once for the whole group.  Members stay independent chains (own seed + chain
+ * id, own table); their tables are bitwise what bnr_chain_run would have produced for each of them alone.  The group
+ * does not own its members: destroy it before (or by) destroying a member.  cb ticks like chain 1's callback. */
+typedef struct bnr_group bnr_group;
+int bnr_group_create(bnr_chain *const *chains, int32_t nchains, bnr_group **out);
+int bnr_group_destroy(bnr_group *group);
+int bnr_group_run(bnr_group *group, int32_t first_index, int32_t nburn, int32_t total, int32_t purge_burn,
+                  int32_t prog_freq, bnr_progress_cb cb, void *user, int32_t *next_row);
+/* options "graph", "graph_k", "overlap", "profiling" as for bnr_chain_set_option / bnr_chain_set_profiling; timings as
+ * bnr_chain_last_timing (which = 1: one k_gram launch covers all members) */
+int bnr_group_set_option(bnr_group *group, const char *name, int64_t value);
+int bnr_group_last_timing(bnr_group *group, int32_t which, double *avg_us, int64_t *launches);
 
 /* gibbs_sample!(state, row, ...) (gibbs.jl:663-677) for one row, and the ten update_*! functions in sweep
  * order (gibbs.jl:267-636): test hooks mirroring test/init-tests.jl:76,96-124.  `row` is 1-based (>= 2);

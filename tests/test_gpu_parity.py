@@ -211,6 +211,63 @@ def test_chains_on_one_gpu_are_independent_and_async(gpu, test1):
     assert_tables_close(alone[1], o.t, what="chain 2")
 
 
+def test_lockstep_group_equals_chains_alone(gpu, test1):
+    """bnr_group_run: several chains of one fit on one GPU advance together (one launch per kernel, blockIdx.z = chain).
+    Every member's table must be bitwise what the chain produces alone -- over the purge ring, a continuation call, all
+    launch modes, a progress callback, and a ragged size whose n is not a multiple of the tile sizes."""
+    X, y = test1
+    Xr, yr, _ = bnr_amd.make_synthetic(37, 9, 3, seed=5)
+    # (X, y, R, table length, [run! calls (first_index, nburn, total, purge_burn)])
+    cases = [(X, y, 5, 14, [(2, 20, 30, 4)]),                       # purge ring: 30 iterations in a 14-row table
+             (X, y, 5, 30, [(2, 12, 9, None), (10, 12, 30, None)]),  # continuation (run! with first_index > 2)
+             (Xr, yr, 3, 21, [(2, 5, 9, None), (10, 5, 21, None)])]
+    for Xc, yc, R, tot, calls in cases:
+        alone = []
+        for c in (1, 2, 3, 4):
+            ch = bnr_amd.Chain(Xc, yc, R, tot, 77, c)
+            ch.init_prior()
+            for call in calls:
+                ch.run(*call)
+            alone.append(ch.fetch())
+            ch.close()
+        assert not np.array_equal(alone[0]["gamma"], alone[1]["gamma"])
+        for opts in ({}, {"graph": 0}, {"overlap": 0, "graph_k": 3}):
+            chains = [bnr_amd.Chain(Xc, yc, R, tot, 77, 1)]
+            chains += [bnr_amd.Chain.like(chains[0], 77, c) for c in (2, 3, 4)]        # X, y shared on the device
+            for ch in chains:
+                ch.init_prior()
+            g = bnr_amd.Group(chains)
+            for k, v in opts.items():
+                g.set_option(k, v)
+            ticks = []
+            for i, call in enumerate(calls):
+                g.run(*call, prog_freq=4, callback=(lambda done: ticks.append(done)) if i == 0 else None)
+            first = calls[0]
+            assert ticks == [d for d in range(1, first[2] - first[0] + 2) if (first[0] + d - 1) % 4 == 0]   # gibbs.jl:854-856
+            for ch, ref in zip(chains, alone):
+                got = ch.fetch()
+                for k in bo.COLUMNS:
+                    assert np.array_equal(got[k], ref[k]), (opts, k)
+                assert ch.counters()["chol_fail"] == 0
+            g.close()
+            for ch in chains:
+                ch.close()
+    a, b = bnr_amd.Chain(X, y, 5, 10, 1, 1), bnr_amd.Chain(Xr, yr, 3, 10, 1, 2)
+    with pytest.raises(bnr_amd.BnrError):
+        bnr_amd.Group([a, b])                                        # unequal shapes
+    # the shared inputs outlive the chain that uploaded them
+    c2 = bnr_amd.Chain.like(a, 1, 2)
+    a.close()
+    c2.init_prior()
+    c2.run(2, 10, 10)
+    ref = bnr_amd.Chain(X, y, 5, 10, 1, 2)
+    ref.init_prior()
+    ref.run(2, 10, 10)
+    assert np.array_equal(c2.fetch()["gamma"], ref.fetch()["gamma"])
+    for ch in (b, c2, ref):
+        ch.close()
+
+
 def test_generate_samples_end_to_end(gpu, test1, tmp_path):
     """generate_samples! / Fit! drop-in (gibbs.jl:725-751, 897-1020): Results layout, Rhat over 2 chains, top-up loop."""
     X, y = test1
