@@ -150,23 +150,27 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     d.n_pad = round_up(n, BNR_GT);
     d.ntile = d.n_pad / BNR_GT;
     const int ntl = d.ntile * (d.ntile + 1) / 2;
-    // split K so that the Gram launch fills the chip in whole rounds of one 1024-thread workgroup per CU: a grid of
-    // 288 workgroups on 256 CUs runs two rounds and takes twice as long as one of 252 (measured: 58 vs 31 us)
+    // split K so that the Gram launch fills the chip in whole rounds of resident workgroups (gram_kg = 4: one 1024-thread
+    // workgroup per CU; 2: two 512-thread workgroups): a grid of 288 x 1024 threads on 256 CUs runs two rounds and takes
+    // twice as long as one of 252 (measured: 58 vs 31 us)
     {
         hipDeviceProp_t prop;
         int ncu = 256;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        const char *ev = getenv("BNR_GRAM_KG");
+        d.gram_kg = (ev && atoi(ev) == 4) ? 4 : 2;
+        const int slots = ncu * (4 / d.gram_kg);
         double best = -1.0;
         d.ksplit = 1;
-        for (int ks = 1; ks <= 16; ++ks) {
-            if (ks > 1 && (d.q + ks - 1) / ks < 128) break;                 // keep every K slice at least 128 columns
+        for (int ks = 1; ks <= 32; ++ks) {
+            if (ks > 1 && (d.q + ks - 1) / ks < 32 * d.gram_kg) break;      // keep every K-group at least 32 columns long
             long tasks = (long)ntl * ks;
-            double eff = (double)tasks / (double)(((tasks + ncu - 1) / ncu) * ncu);
-            double score = eff - 0.01 * ks;                                   // fewer split-K partials when efficiency ties
+            double eff = (double)tasks / (double)(((tasks + slots - 1) / slots) * slots);
+            double score = eff - 0.005 * ks;                                  // fewer split-K partials when efficiency ties
             if (score > best) { best = score; d.ksplit = ks; }
         }
     }
-    int kchunk = round_up((d.q + d.ksplit - 1) / d.ksplit, 32);
+    int kchunk = round_up((d.q + d.ksplit - 1) / d.ksplit, 8 * d.gram_kg);
     d.q_pad = kchunk * d.ksplit;
     // row layout
     int o = 4;
@@ -221,19 +225,24 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
             hipMemcpy(el, hl.data(), d.q * sizeof(int), hipMemcpyHostToDevice);
         }
         {
-            // XCD-aware task map of k_gram (tasks = lower tiles x K slices)
+            // XCD-aware task map of k_gram (tasks = lower tiles x K slices): workgroup i runs on XCD i % 8; give it a K
+            // slice ks with ks % 8 == i % 8 while there are any, so that a slice of X is read through one XCD's L2
             const int ntask = ntl * d.ksplit;
-            std::vector<int> map(ntask, -1), next_tile(d.ksplit, 0);
+            std::vector<int> map(ntask, -1);
+            std::vector<std::vector<int>> queue(8);
+            for (int t = 0; t < ntl; ++t)
+                for (int ks = 0; ks < d.ksplit; ++ks) queue[ks % 8].push_back(t | (ks << 16));
+            std::vector<size_t> head(8, 0);
             std::vector<int> later;
             for (int i = 0; i < ntask; ++i) {
                 int x = i % 8;
-                if (x < d.ksplit && next_tile[x] < ntl) { map[i] = next_tile[x] | (x << 16); next_tile[x]++; }
+                if (head[x] < queue[x].size()) map[i] = queue[x][head[x]++];
                 else later.push_back(i);
             }
-            int ks = 0;
+            int xq = 0;
             for (int i : later) {
-                while (ks < d.ksplit && next_tile[ks] >= ntl) ++ks;
-                map[i] = next_tile[ks] | (ks << 16); next_tile[ks]++;
+                while (xq < 8 && head[xq] >= queue[xq].size()) ++xq;
+                map[i] = queue[xq][head[xq]++];
             }
             TRY(in_alloc((void **)&gm, sizeof(int) * ntask));
             hipMemcpy(gm, map.data(), ntask * sizeof(int), hipMemcpyHostToDevice);
@@ -386,7 +395,13 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
         e0 = x.ev[2 * s]; e1 = x.ev[2 * s + 1];
         hipEventRecord(e0, st);
     }
-    BNR_LAUNCH(k_gram, dim3(round_up(ntl * d.ksplit, 8), 1, x.nb), dim3(1024), 0, st, x, s);
+    if (d.gram_kg == 4) {
+        if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), dim3(round_up(ntl * d.ksplit, 8)), dim3(1024), 0, st, bnr_one{d}, s);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_many, 4>), dim3(round_up(ntl * d.ksplit, 8), 1, x.nb), dim3(1024), 0, st, bnr_many{x.cds}, s);
+    } else {
+        if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 2>), dim3(round_up(ntl * d.ksplit, 8)), dim3(512), 0, st, bnr_one{d}, s);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_many, 2>), dim3(round_up(ntl * d.ksplit, 8), 1, x.nb), dim3(512), 0, st, bnr_many{x.cds}, s);
+    }
     if (timed) hipEventRecord(e1, st);
     BNR_LAUNCH(k_gram_reduce, dim3(ntl, 8, x.nb), dim3(256), 0, st, x, s);
 }
@@ -394,8 +409,11 @@ static void launch_rhs(bnr_exec &x, int s) { BNR_LAUNCH(k_rhs, dim3(x.shape->n_p
 static void launch_chol(bnr_exec &x, int s, hipStream_t st)
 {
     const int nbk = x.shape->n_pad / BNR_NB;
+    // update workgroups take `tpw` blocks each: one for a single chain (they are off the critical path and there are few),
+    // four in a group so that panels + updates of all members fit the chip in one round (2 workgroups per CU)
+    const int tpw = x.nb > 1 ? 4 : 1;
     for (int p = 0; p < nbk; ++p)
-        BNR_LAUNCH(k_chol_step, dim3(bnr_chol_npanel(nbk, p) + bnr_chol_ntile(nbk, p), 1, x.nb), dim3(256), 0, st, x, p, s);
+        BNR_LAUNCH(k_chol_step, dim3(x.nb, bnr_chol_npanel(nbk, p) + (bnr_chol_ntile(nbk, p) + tpw - 1) / tpw), dim3(256), 0, st, x, p, s, tpw);
 }
 static void launch_solve(bnr_exec &x)
 {
@@ -1055,6 +1073,13 @@ int bnr_chain_debug_copy(bnr_chain *c, int32_t which, double *out, int64_t count
     return BNR_OK;
 }
 
+static void launch_gram_only(bnr_chain *c)
+{
+    const bnr_dev &d = c->d;
+    const int ntl = d.ntile * (d.ntile + 1) / 2;
+    if (d.gram_kg == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), dim3(round_up(ntl * d.ksplit, 8)), dim3(1024), 0, c->x.stream, bnr_one{d}, 0);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 2>), dim3(round_up(ntl * d.ksplit, 8)), dim3(512), 0, c->x.stream, bnr_one{d}, 0);
+}
 int bnr_chain_debug_time_gram(bnr_chain *c, int32_t reps, double *avg_us)
 {
     if (!c || !avg_us || reps < 1) return fail(BNR_ERR_BAD_ARG, "bad argument");
@@ -1066,12 +1091,11 @@ int bnr_chain_debug_time_gram(bnr_chain *c, int32_t reps, double *avg_us)
     int rc = upload_plan(c, 1);
     if (rc) return rc;
     const bnr_dev &d = c->d;
-    const int ntl = d.ntile * (d.ntile + 1) / 2;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one>), dim3(round_up(ntl * d.ksplit, 8)), dim3(1024), 0, c->x.stream, bnr_one{c->d}, 0);
+    for (int w = 0; w < 3; ++w) launch_gram_only(c);
     hipEventRecord(e0, c->x.stream);
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one>), dim3(gridsz ? gridsz : round_up(ntl * d.ksplit, 8)), dim3(1024), 0, c->x.stream, bnr_one{c->d}, 0);
+    for (int r = 0; r < reps; ++r) launch_gram_only(c);
     hipEventRecord(e1, c->x.stream);
     HIPCHK(hipStreamSynchronize(c->x.stream));
     float ms = 0;

@@ -46,7 +46,7 @@ struct bnr_dev {
     double *PG;                  // nblk_x x n_pad GEMV partials (X gamma, refresh path)
     int nblk_x, chunk_x;
     double *Gpart, *E;           // Gram partial tiles; E = extended matrix of the factorization (see k_gram_reduce)
-    int ksplit, ntile;           // ntile = n_pad/64
+    int ksplit, ntile, gram_kg;  // ntile = n_pad/64; gram_kg = K-groups per k_gram workgroup (2 or 4)
     const int *gmap;             // k_gram: workgroup id -> (tile | ks << 16), XCD-aware (K slice x on the workgroups of XCD label x)
     double *a3, *xw, *a4, *res, *xg, *bw, *wv;   // n_pad each (bw: right-hand side b = a1 - a3; wv: w = L^-1 b)
     double *scal;                // [0]=rr (sum res^2), [1]=sig_q (sum (g^2/2)/S), [2]=tau (sqrt tau2 of current row), [3..4] pre-drawn tau2
@@ -61,8 +61,18 @@ struct bnr_dev {
 // How a sweep kernel finds its chain.  One chain: the struct travels by value in the kernel arguments (no dependent
 // load in front of the first useful one -- the sweep of a single chain is a latency chain of ~30 launches).  Lockstep
 // group: a device array indexed by blockIdx.z (one more scalar load, paid once per launch for all members).
-struct bnr_one { bnr_dev d; __device__ __forceinline__ const bnr_dev &get() const { return d; } };
-struct bnr_many { const bnr_dev *p; __device__ __forceinline__ const bnr_dev &get() const { return p[blockIdx.z]; } };
+// get_x(): kernels whose grid is (chain, workgroup) -- chain fastest, so that the workgroups with the same role of all
+// members are dispatched together (k_chol_step: every member's panel workgroups before anybody's update workgroups).
+struct bnr_one {
+    bnr_dev d;
+    __device__ __forceinline__ const bnr_dev &get() const { return d; }
+    __device__ __forceinline__ const bnr_dev &get_x() const { return d; }
+};
+struct bnr_many {
+    const bnr_dev *p;
+    __device__ __forceinline__ const bnr_dev &get() const { return p[blockIdx.z]; }
+    __device__ __forceinline__ const bnr_dev &get_x() const { return p[blockIdx.x]; }
+};
 
 enum { ROW_TAU2 = 0, ROW_THETA = 1, ROW_DELTA = 2, ROW_MU = 3 };
 enum { SC_RR = 0, SC_SIGQ = 1, SC_TAU = 2, SC_TAU2N = 3, SC_TAU2N_IT = 4 };   // TAU2N: tau2 pre-drawn by k_tail for iteration id TAU2N_IT
@@ -398,18 +408,20 @@ __global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int w
 // blockIdx.y = K slice across workgroups (split-K partials, summed by k_gram_reduce).
 typedef double bnr_d4 __attribute__((ext_vector_type(4)));
 typedef double bnr_d2 __attribute__((ext_vector_type(2)));
-#define BNR_GRAM_KG 4
 #define BNR_GRAM_KB 8                 // columns of X per staged batch (2 MFMA k-steps)
 #define BNR_GRAM_CS 80                // LDS column stride in doubles: 64 rows + 16 pad -> conflict-free ds_read_b64 fragments
 
 // LDS-staged, double-buffered K loop.  Per K-group (4 waves = 256 threads) and batch: the j-side panel X[j-rows, 8 cols]
 // and the S-scaled i-side panel are loaded one batch ahead with coalesced 16-byte global loads (registers), written to
 // LDS [col][row] with a padded column stride, and read back as MFMA fragments with ds_read_b64.
-template <class SRC>
-__global__ __launch_bounds__(1024) void k_gram(const SRC chain_src, int s)
+// KG = K-groups per workgroup.  KG = 4: 1024 threads, one workgroup per CU.  KG = 2: 512 threads and 64 KiB of LDS, TWO
+// workgroups per CU, so that the prologue (first loads), the K-group reduction and the store of one workgroup overlap
+// with the MFMA loop of its neighbour when a launch runs for several rounds (lockstep groups).
+template <class SRC, int KG>
+__global__ __launch_bounds__(KG * 256) void k_gram(const SRC chain_src, int s)
 {
     const bnr_dev &cd = chain_src.get();
-    __shared__ double sred[BNR_GRAM_KG * BNR_GT * BNR_GT];     // 128 KiB: staging buffers during the loop, then the K-group reduction
+    __shared__ double sred[KG * BNR_GT * BNR_GT];     // staging buffers during the loop, then the K-group reduction
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     const double *Sp = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
     // workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD); the host-built map gives the
@@ -433,7 +445,7 @@ __global__ __launch_bounds__(1024) void k_gram(const SRC chain_src, int s)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kg = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
     const int kchunk = cd.q_pad / cd.ksplit;          // multiple of 32 (host guarantees)
-    const int ksub = kchunk / BNR_GRAM_KG;            // multiple of 8
+    const int ksub = kchunk / KG;                     // multiple of 8
     const int eb = ks * kchunk + kg * ksub;
     const int nbatch = ksub / BNR_GRAM_KB;
     const size_t ld = cd.n_pad;
@@ -452,18 +464,23 @@ __global__ __launch_bounds__(1024) void k_gram(const SRC chain_src, int s)
     // register prefetch two batches deep, loop unrolled by two so that the register sets alternate without moves
     bnr_d2 riA, rjA, riB, rjB;
     double svA, svB;
+#ifndef BNR_GRAM_EXP
+#define BNR_GRAM_EXP 0        // timing experiments only (tools/gram_experiments.sh): 1 no S scaling, 2 no global loads in the loop, 3 both
+#endif
 #define BNR_GRAM_LOAD(RI, RJ, SV, BIDX)                                                                   \
     do {                                                                                                  \
-        const double *cb_ = xb + (size_t)(BIDX) * (BNR_GRAM_KB * ld);                                     \
+        const double *cb_ = xb + (size_t)(((BNR_GRAM_EXP & 2) && (BIDX) > 2) ? 0 : (BIDX)) * (BNR_GRAM_KB * ld); \
         int si_ = (BIDX) * BNR_GRAM_KB + c;                                                               \
-        SV = sb[si_ < smax ? si_ : smax];                                                                 \
-        RI = *(const bnr_d2 *)(cb_ + offI);                                                               \
-        RJ = *(const bnr_d2 *)(cb_ + offJ);                                                               \
+        if (!(BNR_GRAM_EXP & 1)) SV = sb[si_ < smax ? si_ : smax]; else SV = 1.0;                         \
+        if (!(BNR_GRAM_EXP & 2) || (BIDX) <= 2) {                                                         \
+            RI = *(const bnr_d2 *)(cb_ + offI);                                                           \
+            RJ = *(const bnr_d2 *)(cb_ + offJ);                                                           \
+        }                                                                                                 \
     } while (0)
 #define BNR_GRAM_STORE(RI, RJ, SV, BUF)                                                                   \
     do {                                                                                                  \
         double *nx_ = stg + (size_t)(BUF) * (2 * PANEL);                                                  \
-        *(bnr_d2 *)(nx_ + woff) = RI * SV;                                                                \
+        *(bnr_d2 *)(nx_ + woff) = (BNR_GRAM_EXP & 1) ? RI : RI * SV;                                      \
         *(bnr_d2 *)(nx_ + PANEL + woff) = RJ;                                                             \
     } while (0)
 #define BNR_GRAM_COMPUTE(BUF)                                                                             \
@@ -515,8 +532,10 @@ __global__ __launch_bounds__(1024) void k_gram(const SRC chain_src, int s)
     __syncthreads();
     double *out = cd.Gpart + ((size_t)ks * (cd.ntile * (cd.ntile + 1) / 2) + t) * (BNR_GT * BNR_GT);
 #pragma unroll
-    for (int idx = threadIdx.x; idx < BNR_GT * BNR_GT; idx += 1024)
-        out[idx] = (sred[idx] + sred[BNR_GT * BNR_GT + idx]) + (sred[2 * BNR_GT * BNR_GT + idx] + sred[3 * BNR_GT * BNR_GT + idx]);
+    for (int idx = threadIdx.x; idx < BNR_GT * BNR_GT; idx += KG * 256) {
+        if (KG == 4) out[idx] = (sred[idx] + sred[BNR_GT * BNR_GT + idx]) + (sred[2 * BNR_GT * BNR_GT + idx] + sred[3 * BNR_GT * BNR_GT + idx]);
+        else out[idx] = sred[idx] + sred[BNR_GT * BNR_GT + idx];
+    }
     BNR_GSTAMP(3);
 #ifdef BNR_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < 256) cd.dbg[768 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -721,9 +740,9 @@ __device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &
     return bad;
 }
 template <class SRC>
-__global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p, int s)
+__global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p, int s, int tpw)
 {
-    const bnr_dev &cd = chain_src.get();
+    const bnr_dev &cd = chain_src.get_x();               // grid = (chains, workgroups): blockIdx.x = chain, blockIdx.y = workgroup
     __shared__ bnr_panel_lds sh;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nbk = cd.n_pad / BNR_NB;
     const size_t ld = bnr_ldE(cd.n_pad);
@@ -732,32 +751,35 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
     const int mt = wave >> 1, nt = wave & 1;               // this wave's 16x16 tile of a 32x32 block: columns mt, rows nt
     const int ln = lane & 15, lq = lane >> 4;
     double *E = cd.E;
-    if ((int)blockIdx.x >= npanel) {
-        // ------------------------------------------------ role B: E[rho,j] -= L[rho,p-1] L[j,p-1]'
+    if ((int)blockIdx.y >= npanel) {
+        // ------------------------------------------------ role B: E[rho,j] -= L[rho,p-1] L[j,p-1]', tpw blocks per workgroup
         const int m = nbk - (p + 1);
-        int t = blockIdx.x - npanel, rho, j;
-        const int ntri = m * (m + 1) / 2;
-        if (t < ntri) {
-            int ti = 0;
-            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-            int tj = t - ti * (ti + 1) / 2;
-            rho = p + 1 + ti; j = p + 1 + tj;
-        } else {
-            t -= ntri;
-            j = p + 1 + t / p;
-            rho = nbk + t % p;                             // identity block row
+        const int ntri = m * (m + 1) / 2, ntot = bnr_chol_ntile(nbk, p);
+        const int t0 = ((int)blockIdx.y - npanel) * tpw;
+        for (int tt = 0; tt < tpw && t0 + tt < ntot; ++tt) {
+            int t = t0 + tt, rho, j;
+            if (t < ntri) {
+                int ti = 0;
+                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+                int tj = t - ti * (ti + 1) / 2;
+                rho = p + 1 + ti; j = p + 1 + tj;
+            } else {
+                t -= ntri;
+                j = p + 1 + t / p;
+                rho = nbk + t % p;                         // identity block row
+            }
+            double *cp = E + (size_t)(rho * BNR_NB + nt * 16 + ln) + ld * (size_t)(j * BNR_NB + mt * 16 + lq);
+            bnr_d4 c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] = cp[ld * (size_t)(4 * r)];
+            c = bnr_tile_update(E + (size_t)(j * BNR_NB + mt * 16) + ld * (size_t)kc, E + (size_t)(rho * BNR_NB + nt * 16) + ld * (size_t)kc, ld, lane, c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cp[ld * (size_t)(4 * r)] = c[r];
         }
-        double *cp = E + (size_t)(rho * BNR_NB + nt * 16 + ln) + ld * (size_t)(j * BNR_NB + mt * 16 + lq);
-        bnr_d4 c;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) c[r] = cp[ld * (size_t)(4 * r)];
-        c = bnr_tile_update(E + (size_t)(j * BNR_NB + mt * 16) + ld * (size_t)kc, E + (size_t)(rho * BNR_NB + nt * 16) + ld * (size_t)kc, ld, lane, c);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cp[ld * (size_t)(4 * r)] = c[r];
         return;
     }
     // ---------------------------------------------------- role A: panel workgroup
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
     if (p == 0 && b == 0) {
         // cheap safety net for the two-branch schedule: every k_gram_reduce workgroup of THIS sweep must have finished
         const unsigned int it = cd.plan[cd.pbase[0] + s].it;

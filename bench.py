@@ -5,9 +5,11 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = one Gibbs sweep (gibbs_sample!, gibbs.jl:663-677) of every chain resident on the GPU.  Workload: synthetic
-n=500, V=100 (q=5050), R=7 (SURVEY.md 8d generator, seed 20240501), one chain per GPU (BASELINE.json configs[2]:
-"8 chains on 8xMI355X, one chain/GPU"), weak scaling: per-GPU work is fixed, chains are independent, no data-path
-collective; after the timed region the per-chain split-Rhat messages are all-gathered over RCCL (reported, not timed).
+n=500, V=100 (q=5050), R=7 (SURVEY.md 8d generator, seed 20240501), the 8 chains of BASELINE.json configs[2] on every
+GPU (they advance as one lockstep group: one launch per kernel for all of them), weak scaling: per-GPU work is fixed,
+chains are independent, no data-path collective; after the timed region the per-chain split-Rhat messages are
+all-gathered over RCCL (reported, not timed).  The same line also carries the latency-bound figure of configs[2]'s
+literal layout, ONE chain per GPU ("single_chain"), measured in the same process.
 Inputs are resident in HBM when the timed region starts.  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -28,20 +30,42 @@ CONFIGS = {
 FP64_MFMA_PEAK_TFLOPS = 78.6               # AMD MI355X FP64 matrix spec (not in the local guide)
 
 
-def cpu_baseline(X, y, R, seed, budget_s=15.0):
-    """The CPU oracle in reference-cost mode (full 2n^2 q GEMM, LU solve, dense (V-1)-dim pdfs) on the host cores."""
-    from oracle import bnr_oracle as bo
-    tot = 64
-    o = bo.Oracle(X, y, R, tot, seed, chain=1, pdf_mode=0, cost_mode=1)
-    o.init_prior()
-    t0 = time.time()
-    done = 0
-    while done < tot - 1 and (done < 2 or time.time() - t0 < budget_s):
-        o.gibbs_sample(done + 1, done + 2)
-        done += 1
-    dt = time.time() - t0
-    return dict(value=done / dt, unit="Gibbs iterations/s (1 chain)", cores=bo.lib().orc_num_threads(), kind="port",
-                sample="%d iterations of the same n/V/R workload, 1 chain, OpenMP over the Gram columns" % done)
+_CPU_WORKER = r"""
+import sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import bnr_amd
+from oracle import bnr_oracle as bo
+n, V, R, seed, chain, budget = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), float(sys.argv[7])
+X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=seed)
+tot = 256
+o = bo.Oracle(X, y, R, tot, seed, chain=chain, pdf_mode=0, cost_mode=1)
+o.init_prior()
+o.gibbs_sample(1, 2)                      # warm-up (page faults, thread pool)
+t0 = time.time(); done = 1
+while done < tot - 1 and (done < 3 or time.time() - t0 < budget):
+    o.gibbs_sample(done + 1, done + 2); done += 1
+print(done - 1, time.time() - t0, bo.lib().orc_num_threads())
+"""
+
+
+def cpu_baseline(n, V, R, seed, nchains, budget_s=15.0):
+    """The CPU oracle in reference-cost mode (full 2n^2 q GEMM, LU solve, dense (V-1)-dim pdfs) on the host cores: the
+    same `nchains` chains as one OS process each (the reference's pmap workers, gibbs.jl:946), the host's hardware
+    threads divided among them (OpenMP over the Gram columns inside a chain).  Iterations/s summed over the chains."""
+    import subprocess
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    per = max(1, ncpu // nchains)
+    env = dict(os.environ, OMP_NUM_THREADS=str(per))
+    procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, str(n), str(V), str(R), str(seed), str(c + 1), str(budget_s)],
+                              stdout=subprocess.PIPE, env=env, text=True) for c in range(nchains)]
+    rate, its, threads = 0.0, 0, 0
+    for p in procs:
+        out = p.communicate(timeout=600)[0].split()
+        its += int(out[0]); rate += int(out[0]) / float(out[1]); threads += int(out[2])
+    return dict(value=rate, unit="Gibbs iterations/s (all chains)", cores=threads, kind="port",
+                sample="%d chains x ~%.0f s of the same n/V/R workload (%d iterations in all), one process per chain with %d "
+                       "OpenMP threads each" % (nchains, budget_s, its, per))
 
 
 def main():
@@ -50,9 +74,10 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
-    ap.add_argument("--chains-per-gpu", type=int, default=1)
+    ap.add_argument("--chains-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=20240501)
+    ap.add_argument("--overlap", type=int, default=1, help="0: single-stream schedule (diagnostics)")
     a = ap.parse_args()
 
     import numpy as np
@@ -84,6 +109,8 @@ def main():
         chains.append(ch)
     # several chains on one GPU advance in lockstep: one launch per kernel of a sweep covers all of them
     runner = bnr_amd.Group(chains) if C > 1 else chains[0]
+    if not a.overlap:
+        runner.set_option("overlap", 0)
 
     def run_all(first, last, profile=False):
         if profile:
@@ -118,6 +145,27 @@ def main():
     gram_us, gram_n = runner.last_timing(1)
     counters = chains[0].counters()
 
+    # configs[2]'s literal layout, one chain per GPU: chain 1 of this rank alone (continues its table; latency-bound)
+    single = None
+    if C > 1:
+        runner.close()
+        runner = None
+        Ks = min(K, 1000)
+        solo = bnr_amd.Chain.like(chains[0], a.seed, rank * C + 1, Ks + 50)
+        solo.init_prior()
+        solo.run(2, 49, 49)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        solo.run(50, Ks + 49, Ks + 49)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t1
+        if dist:
+            t = torch.tensor([dts], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = float(t.item())
+        single = {"value": world * Ks / dts, "unit": "iterations/s", "chains_per_gpu": 1, "steps": Ks, "ms_per_step": 1e3 * dts / Ks}
+        solo.close()
+
     # convergence check over all chains of the job: RCCL all-gather of the per-chain split-Rhat messages
     nsamp = K
     local = {rank * C + lc + 1: ch.rhat_stats(W + 2, nsamp) for lc, ch in enumerate(chains)}
@@ -132,10 +180,9 @@ def main():
         value = total_chains * K / dt
         flops_gram = float(n) * n * q * C                         # algorithmic: symmetric X diag(S) X'  per chain of the launch
         traffic = None                                            # HBM bytes per k_gram launch from the PMC passes (tools/pmc_gram2.sh)
-        pmc_file = os.path.join(ROOT, "profiles", "round1_gram_pmc.json")
-        if a.config == "cfg3" and os.path.exists(pmc_file):
-            traffic = json.load(open(pmc_file)).get("traffic_bytes_per_launch")
-            traffic = traffic * C if traffic is not None else None   # measured on a one-chain launch; a group launch does C times the work
+        pmc_file = os.path.join(ROOT, "profiles", "round1_gram_pmc_kg2.json")
+        if a.config == "cfg3" and C in (1, 8) and os.path.exists(pmc_file):
+            traffic = json.load(open(pmc_file))["one" if C == 1 else "group8"].get("traffic_bytes_per_launch")
         achieved = flops_gram / (gram_us * 1e-6) / 1e12 if gram_us > 0 else 0.0
         out = {
             "metric": "Gibbs iterations/sec (all chains)", "value": value, "unit": "iterations/s",
@@ -145,17 +192,17 @@ def main():
                        "chains_per_gpu": C, "seed": a.seed},
             "roofline": {"bound": "mfma", "kernel": "k_gram (X diag(S) X', v_mfma_f64_16x16x4_f64)", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_source": "profiles/round1_gram_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
+                         "traffic": traffic, "traffic_source": "profiles/round1_gram_pmc_kg2.json (FETCH_SIZE x2 + WRITE_SIZE of a launch of this shape, separate --pmc passes, tools/pmc_gram_group.sh)",
                          "flops_per_launch": flops_gram, "avg_launch_us": gram_us, "launches_timed": gram_n,
                          "peak_measured_microbench": 70.0},
             "max_rhat_gamma": float(np.nanmax(rh[:q])), "max_rhat_xi": float(np.nanmax(rh[q:])),
             "counters": counters,
         }
+        if single is not None:
+            out["single_chain"] = single
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(X, y, R, a.seed)
+            out["cpu_baseline"] = cpu_baseline(n, V, R, a.seed, C)
         print(json.dumps(out))
-    if C > 1:
-        runner.close()
     for ch in chains:
         ch.close()
     if dist:
