@@ -323,7 +323,8 @@ static void exec_free(bnr_exec &x)
 // the kernels read the chain's bnr_dev from device memory: refresh the copy whenever the host struct changes
 static int sync_dev(bnr_chain *c)
 {
-    HIPCHK(hipMemcpy(c->x.cds, &c->d, sizeof(bnr_dev), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(c->x.cds, &c->d, sizeof(bnr_dev), hipMemcpyHostToDevice, c->x.stream));   // no legacy-stream calls at run time
+    HIPCHK(hipStreamSynchronize(c->x.stream));
     return BNR_OK;
 }
 
@@ -333,7 +334,12 @@ int bnr_chain_destroy(bnr_chain *c)
 {
     if (!c) return BNR_OK;
     hipSetDevice(c->device);
-    if (c->group) bnr_group_destroy(c->group);          // a group cannot outlive a member
+    if (c->group) {                                      // a group cannot run without a member: dissolve it (the handle stays valid)
+        bnr_group *g = c->group;
+        hipStreamSynchronize(g->x.stream);
+        for (bnr_chain *m : g->m) m->group = nullptr;
+        g->m.clear();
+    }
     exec_free(c->x);
     for (void *p : c->allocs) hipFree(p);
     if (c->d.trace) hipFree(c->d.trace);
@@ -486,7 +492,7 @@ static int launch_range(bnr_exec &x, int count)
         while (count - done >= K) {
             if (!x.gexec) {
                 x.fj_next = 0;
-                HIPCHK(hipStreamBeginCapture(x.stream, hipStreamCaptureModeRelaxed));
+                HIPCHK(hipStreamBeginCapture(x.stream, hipStreamCaptureModeThreadLocal));   // other host threads may drive other handles meanwhile
                 for (int s = 0; s < K; ++s) launch_sweep(x, s, true);
                 hipLaunchKernelGGL(k_advance, dim3(x.nb), dim3(1), 0, x.stream, (const bnr_dev *)x.cds, K);
                 HIPCHK(hipStreamEndCapture(x.stream, &x.graph));
@@ -682,6 +688,7 @@ int bnr_group_run(bnr_group *g, int32_t first_index, int32_t nburn, int32_t tota
                   int32_t prog_freq, bnr_progress_cb cb, void *user, int32_t *next_row)
 {
     if (!g) return fail(BNR_ERR_BAD_ARG, "NULL group");
+    if (g->m.empty()) return fail(BNR_ERR_BAD_ARG, "the group was dissolved (one of its chains was destroyed)");
     HIPCHK(hipSetDevice(g->x.device));
     for (bnr_chain *c : g->m) {
         if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending on a member");
@@ -696,7 +703,8 @@ int bnr_group_run(bnr_group *g, int32_t first_index, int32_t nburn, int32_t tota
     }
     std::vector<bnr_dev> host;
     for (bnr_chain *c : g->m) { HIPCHK(hipStreamSynchronize(c->x.stream)); host.push_back(c->d); }
-    HIPCHK(hipMemcpy(g->x.cds, host.data(), sizeof(bnr_dev) * host.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(g->x.cds, host.data(), sizeof(bnr_dev) * host.size(), hipMemcpyHostToDevice, g->x.stream));
+    HIPCHK(hipStreamSynchronize(g->x.stream));
     rc = run_exec(g->x, first_index, count, prog_freq, cb, user);
     if (rc) return rc;
     for (bnr_chain *c : g->m) {
@@ -1050,7 +1058,8 @@ int bnr_chain_counters(bnr_chain *c, int64_t out[8])
 {
     if (!c || !out) return fail(BNR_ERR_BAD_ARG, "NULL argument");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpy(c->counters_host, c->d.counters, sizeof(long long) * 16, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(c->counters_host, c->d.counters, sizeof(long long) * 16, hipMemcpyDeviceToHost, c->x.stream));
+    HIPCHK(hipStreamSynchronize(c->x.stream));
     for (int i = 0; i < 8; ++i) out[i] = c->counters_host[i];   // [4..7]: where a hard Cholesky failure happened (node, Psi, M, G+I)
     return BNR_OK;
 }

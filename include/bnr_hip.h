@@ -83,7 +83,8 @@ int bnr_chain_sync(bnr_chain *chain, int32_t *next_row);
  * bnr_group_run is run! (gibbs.jl:849-864) for every member with the same (first_index, nburn, total, purge_burn),
  * each kernel of a sweep being launched once for the whole group.  Members stay independent chains (own seed + chain
  * id, own table); their tables are bitwise what bnr_chain_run would have produced for each of them alone.  The group
- * does not own its members: destroy it before (or by) destroying a member.  cb ticks like chain 1's callback. */
+ * does not own its members; destroying a member dissolves the group (its handle stays valid until bnr_group_destroy,
+ * bnr_group_run then fails).  cb ticks like chain 1's callback. */
 typedef struct bnr_group bnr_group;
 int bnr_group_create(bnr_chain *const *chains, int32_t nchains, bnr_group **out);
 int bnr_group_destroy(bnr_group *group);
