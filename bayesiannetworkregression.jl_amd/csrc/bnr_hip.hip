@@ -401,12 +401,13 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
         e0 = x.ev[2 * s]; e1 = x.ev[2 * s + 1];
         hipEventRecord(e0, st);
     }
+    const dim3 ggrid(round_up(ntl * d.ksplit, 8) * x.nb);
     if (d.gram_kg == 4) {
-        if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), dim3(round_up(ntl * d.ksplit, 8)), dim3(1024), 0, st, bnr_one{d}, s);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_many, 4>), dim3(round_up(ntl * d.ksplit, 8), 1, x.nb), dim3(1024), 0, st, bnr_many{x.cds}, s);
+        if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), ggrid, dim3(1024), 0, st, bnr_one{d}, s, 1);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_many, 4>), ggrid, dim3(1024), 0, st, bnr_many{x.cds}, s, x.nb);
     } else {
-        if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 2>), dim3(round_up(ntl * d.ksplit, 8)), dim3(512), 0, st, bnr_one{d}, s);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_many, 2>), dim3(round_up(ntl * d.ksplit, 8), 1, x.nb), dim3(512), 0, st, bnr_many{x.cds}, s);
+        if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 2>), ggrid, dim3(512), 0, st, bnr_one{d}, s, 1);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_many, 2>), ggrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb);
     }
     if (timed) hipEventRecord(e1, st);
     BNR_LAUNCH(k_gram_reduce, dim3(ntl, 8, x.nb), dim3(256), 0, st, x, s);
@@ -1086,8 +1087,8 @@ static void launch_gram_only(bnr_chain *c)
 {
     const bnr_dev &d = c->d;
     const int ntl = d.ntile * (d.ntile + 1) / 2;
-    if (d.gram_kg == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), dim3(round_up(ntl * d.ksplit, 8)), dim3(1024), 0, c->x.stream, bnr_one{d}, 0);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 2>), dim3(round_up(ntl * d.ksplit, 8)), dim3(512), 0, c->x.stream, bnr_one{d}, 0);
+    if (d.gram_kg == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), dim3(round_up(ntl * d.ksplit, 8)), dim3(1024), 0, c->x.stream, bnr_one{d}, 0, 1);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 2>), dim3(round_up(ntl * d.ksplit, 8)), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1);
 }
 int bnr_chain_debug_time_gram(bnr_chain *c, int32_t reps, double *avg_us)
 {

@@ -67,11 +67,15 @@ struct bnr_one {
     bnr_dev d;
     __device__ __forceinline__ const bnr_dev &get() const { return d; }
     __device__ __forceinline__ const bnr_dev &get_x() const { return d; }
+    __device__ __forceinline__ const bnr_dev &at(int) const { return d; }
+    static constexpr bool many = false;
 };
 struct bnr_many {
     const bnr_dev *p;
     __device__ __forceinline__ const bnr_dev &get() const { return p[blockIdx.z]; }
     __device__ __forceinline__ const bnr_dev &get_x() const { return p[blockIdx.x]; }
+    __device__ __forceinline__ const bnr_dev &at(int c) const { return p[c]; }
+    static constexpr bool many = true;
 };
 
 enum { ROW_TAU2 = 0, ROW_THETA = 1, ROW_DELTA = 2, ROW_MU = 3 };
@@ -417,10 +421,15 @@ typedef double bnr_d2 __attribute__((ext_vector_type(2)));
 // KG = K-groups per workgroup.  KG = 4: 1024 threads, one workgroup per CU.  KG = 2: 512 threads and 64 KiB of LDS, TWO
 // workgroups per CU, so that the prologue (first loads), the K-group reduction and the store of one workgroup overlap
 // with the MFMA loop of its neighbour when a launch runs for several rounds (lockstep groups).
+// Grid (1-D) = round_up(tasks, 8) x chains.  Workgroup id -> XCD label id % 8 (round-robin dispatch), and within one
+// XCD's sequence the chains of a lockstep group are innermost: the 8 (or C) workgroups that need the same panels of X
+// (same tile, same K slice, different S) run next to each other on the same XCD and share them through its L2.
 template <class SRC, int KG>
-__global__ __launch_bounds__(KG * 256) void k_gram(const SRC chain_src, int s)
+__global__ __launch_bounds__(KG * 256) void k_gram(const SRC chain_src, int s, int nchains)
 {
-    const bnr_dev &cd = chain_src.get();
+    const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
+    const int gchain = gr % nchains, gslot = (gr / nchains) * 8 + gx;      // gslot: position in the one-chain task map
+    const bnr_dev &cd = chain_src.at(gchain);
     __shared__ double sred[KG * BNR_GT * BNR_GT];     // staging buffers during the loop, then the K-group reduction
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     const double *Sp = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
@@ -435,9 +444,9 @@ __global__ __launch_bounds__(KG * 256) void k_gram(const SRC chain_src, int s)
 #ifdef BNR_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < 256) { cd.dbg[512 + blockIdx.x] = __builtin_amdgcn_s_memrealtime(); unsigned xcc = __builtin_amdgcn_s_getreg((20 | (0 << 6) | (3 << 11))); unsigned hwid = __builtin_amdgcn_s_getreg((4 | (0 << 6) | (31 << 11))); cd.dbg[256 + blockIdx.x] = ((unsigned long long)xcc << 32) | hwid; }
 #endif
-    // the grid's x extent is padded to a multiple of 8 so that blockIdx.x % 8 labels the XCD for every member of a group
-    if ((int)blockIdx.x >= cd.ksplit * (cd.ntile * (cd.ntile + 1) / 2)) return;
-    const int task = cd.gmap[blockIdx.x];
+    // the task map's extent is padded to a multiple of 8 so that id % 8 labels the XCD
+    if (gslot >= cd.ksplit * (cd.ntile * (cd.ntile + 1) / 2)) return;
+    const int task = cd.gmap[gslot];
     int t = task & 0xFFFF, ti = 0;
     const int ks = task >> 16;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;

@@ -268,6 +268,51 @@ def test_lockstep_group_equals_chains_alone(gpu, test1):
         ch.close()
 
 
+def test_handles_can_be_driven_from_different_host_threads(gpu, test1):
+    """ABI contract (threading): a handle is not shared between threads, but different handles may be driven
+    concurrently from different host threads (the reference runs one chain per pmap worker).  Two groups and a single
+    chain run at the same time -- stream captures included -- and every table equals the chain run alone."""
+    import threading
+    X, y = test1
+    tot = 40
+    alone = {}
+    for c in range(1, 6):
+        ch = bnr_amd.Chain(X, y, 5, tot, 5, c)
+        ch.init_prior()
+        ch.run(2, tot, tot)
+        alone[c] = ch.fetch()
+        ch.close()
+    first = bnr_amd.Chain(X, y, 5, tot, 5, 1)
+    chains = {1: first}
+    for c in range(2, 6):
+        chains[c] = bnr_amd.Chain.like(first, 5, c)
+    for ch in chains.values():
+        ch.init_prior()
+    runners = [bnr_amd.Group([chains[1], chains[2]]), bnr_amd.Group([chains[3], chains[4]]), chains[5]]
+    errors = []
+
+    def work(r):
+        try:
+            r.run(2, tot, tot)
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in runners]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for c, ch in chains.items():
+        got = ch.fetch()
+        for k in bo.COLUMNS:
+            assert np.array_equal(got[k], alone[c][k]), (c, k)
+    for r in runners[:2]:
+        r.close()
+    for ch in chains.values():
+        ch.close()
+
+
 def test_generate_samples_end_to_end(gpu, test1, tmp_path):
     """generate_samples! / Fit! drop-in (gibbs.jl:725-751, 897-1020): Results layout, Rhat over 2 chains, top-up loop."""
     X, y = test1
