@@ -39,7 +39,37 @@ function Chain(X::Matrix{Float64}, y::Vector{Float64}, R, tot_save, seed, c; η=
     ch
 end
 
+# another chain of the same fit on the same GPU: X, y stay shared on the device (bnr_chain_create_like)
+function chain_like(donor::Chain, seed, c, tot_save=donor.tot)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:bnr_chain_create_like, LIB), Cint, (Ptr{Cvoid}, UInt64, Int32, Int32, Ref{Ptr{Cvoid}}), donor.h, UInt64(seed), c, tot_save, out))
+    ch = Chain(out[], donor.n, donor.V, donor.R, donor.q, tot_save)
+    finalizer(x -> ccall((:bnr_chain_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), ch)
+    ch
+end
+
 init_prior!(ch::Chain) = check(ccall((:bnr_chain_init_prior, LIB), Cint, (Ptr{Cvoid},), ch.h))
+
+# lockstep group: the chains of one fit that share a GPU advance together (replaces the pmap over chains, gibbs.jl:946-948)
+mutable struct Group
+    h::Ptr{Cvoid}
+    chains::Vector{Chain}
+end
+function Group(chains::Vector{Chain})
+    hs = Ptr{Cvoid}[ch.h for ch in chains]
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve hs check(ccall((:bnr_group_create, LIB), Cint, (Ptr{Ptr{Cvoid}}, Int32, Ref{Ptr{Cvoid}}), hs, length(hs), out))
+    g = Group(out[], chains)
+    finalizer(x -> ccall((:bnr_group_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), g)
+    g
+end
+function run!(g::Group, first_index, nburn, total, purge_burn; prog_freq=0, tick=nothing)
+    nxt = Ref{Int32}(0)
+    cb = tick === nothing ? C_NULL : @cfunction((u, d) -> (tick(); nothing), Cvoid, (Ptr{Cvoid}, Int64))
+    check(ccall((:bnr_group_run, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}),
+        g.h, first_index, nburn, total, isnothing(purge_burn) ? 0 : purge_burn, prog_freq, cb, C_NULL, nxt))
+    Int(nxt[])
+end
 
 # run!(X,y,state,c,first_index,nburn,total,...,purge_burn,channel)  (gibbs.jl:849-864)
 function run!(ch::Chain, first_index, nburn, total, purge_burn; prog_freq=0, tick=nothing)
