@@ -54,6 +54,7 @@ _SIGS = {
     "bnr_chain_move_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "bnr_chain_resize": (C.c_int, [C.c_void_p, C.c_int32]),
     "bnr_chain_rhat_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
+    "bnr_chain_summary": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]),
     "bnr_rhat_from_stats": (C.c_int, [_dp, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "bnr_chain_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "bnr_chain_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -231,6 +232,12 @@ class Chain:
         out = np.empty(4 * (self.q + self.V))
         check(self.L.bnr_chain_rhat_stats(self.h, first_row, nsamp, _ptr(out)))
         return out
+
+    def summary(self, first_row, nsamp, k_lo, k_hi):
+        """(mean gamma, k_lo-th smallest, k_hi-th smallest per edge, mean xi per node) over the row window, on the device."""
+        mean, lo, hi, pxi = np.empty(self.q), np.empty(self.q), np.empty(self.q), np.empty(self.V)
+        check(self.L.bnr_chain_summary(self.h, first_row, nsamp, k_lo, k_hi, _ptr(mean), _ptr(lo), _ptr(hi), _ptr(pxi)))
+        return mean, lo, hi, pxi
 
     def counters(self):
         out = (C.c_int64 * 8)()

@@ -80,6 +80,7 @@ class Results:
     rhatgamma: np.ndarray
     burn_in: int
     sampled: int
+    summary_device: dict = None      # filled on request: Summary statistics computed on the GPU (see Summary)
 
 
 @dataclass
@@ -105,26 +106,48 @@ def _julia_round(x):
     return int(round(x))
 
 
-def Summary(results, interval=95, digits=3):
-    """gibbs.jl:1214-1250."""
-    nburn, nsamp = results.burn_in, results.sampled
-    total = nburn + nsamp
+def _summary_ranks(nsamp, interval):
+    """1-based positions in the sorted sample the reference reads (gibbs.jl:1224-1233)."""
     lower_bound = (100 - interval) / 200
     upper_bound = 1 - lower_bound
-    g = results.state["gamma"][nburn:total, :, 0]
-    g_sorted = np.sort(g, axis=0)
-    lw = _julia_round(nsamp * lower_bound)
-    hi = _julia_round(nsamp * upper_bound)
-    q = g.shape[1]
+    lw, hi = _julia_round(nsamp * lower_bound), _julia_round(nsamp * upper_bound)
+    if lw < 1 or hi > nsamp:
+        # the reference indexes the sorted vector at 0 here and stops with a BoundsError
+        raise IndexError("Summary: %d samples are too few for a %s%% interval" % (nsamp, interval))
+    return lw, hi
+
+
+def device_summary(chain, nburn, nsamp, interval=95):
+    """Summary statistics of one chain's table computed on the GPU (bnr_chain_summary): only 3q + V numbers cross PCIe."""
+    lw, hi = _summary_ranks(nsamp, interval)
+    mean, lo, up, pxi = chain.summary(nburn + 1, nsamp, lw, hi)
+    return dict(interval=interval, estimate=mean, lower_bound=lo, upper_bound=up, probability=pxi)
+
+
+def Summary(results, interval=95, digits=3):
+    """gibbs.jl:1214-1250.  Uses the statistics computed on the GPU when the fit carried them (summary_interval=...),
+    otherwise sorts the fetched gamma trace on the host like the reference."""
+    nburn, nsamp = results.burn_in, results.sampled
+    total = nburn + nsamp
+    dev = results.summary_device
+    if dev is not None and dev["interval"] == interval:
+        est, lo, up, pxi = dev["estimate"], dev["lower_bound"], dev["upper_bound"], dev["probability"]
+    else:
+        g = results.state["gamma"][nburn:total, :, 0]
+        g_sorted = np.sort(g, axis=0)
+        lw, hi = _summary_ranks(nsamp, interval)
+        est, lo, up = g.mean(axis=0), g_sorted[lw - 1, :], g_sorted[hi - 1, :]
+        pxi = results.state["xi"][nburn:total, :, 0].mean(axis=0)
+    q = est.shape[0]
     V = int((-1 + math.sqrt(1 + 8 * q)) / 2)
     node1, node2 = [], []
     for k in range(1, V + 1):
         for l in range(k, V + 1):
             node1.append(k)
             node2.append(l)
-    edge = dict(node1=np.array(node1), node2=np.array(node2), estimate=np.round(g.mean(axis=0), digits),
-                lower_bound=np.round(g_sorted[lw - 1, :], digits), upper_bound=np.round(g_sorted[hi - 1, :], digits))
-    xi = dict(probability=np.round(results.state["xi"][nburn:total, :, 0].mean(axis=0), digits))
+    edge = dict(node1=np.array(node1), node2=np.array(node2), estimate=np.round(est, digits),
+                lower_bound=np.round(lo, digits), upper_bound=np.round(up, digits))
+    xi = dict(probability=np.round(pxi, digits))
     return BNRSummary(edge, xi, interval)
 
 
@@ -253,15 +276,32 @@ def run(chain, first_index, nburn, total, purge_burn=None, prog_freq=0, callback
     return chain.run(first_index, nburn, total, purge_burn, prog_freq, callback)
 
 
-def return_psrf_VOI(chainset, nburn, nsamp):
-    """gibbs.jl:771-789: PSRF of gamma and xi over rows nburn+1..nburn+nsamp of every chain + chain 1's table."""
+def return_psrf_VOI(chainset, nburn, nsamp, fetch_state=True, summary_interval=None):
+    """gibbs.jl:771-789: PSRF of gamma and xi over rows nburn+1..nburn+nsamp of every chain + chain 1's table.
+    fetch_state=False leaves the table on the device (the top-up loops only look at the PSRF of the intermediate
+    results); summary_interval=<credible level> adds the Summary statistics of chain 1 computed on the device."""
     rg, rx = chainset.rhat(nburn + 1, nsamp)
-    state = None
+    state, dev = None, None
     if 1 in chainset.chains:
         ch = chainset.chains[1]
-        state = new_table(ch.tot, ch.V, ch.R, dead=True)
-        ch.fetch(1, ch.tot, state)
-    return Results(state, rx, rg, nburn, nsamp)
+        if fetch_state:
+            state = new_table(ch.tot, ch.V, ch.R, dead=True)
+            ch.fetch(1, ch.tot, state)
+        if summary_interval is not None:
+            dev = device_summary(ch, nburn, nsamp, summary_interval)
+    return Results(state, rx, rg, nburn, nsamp, dev)
+
+
+def _finish(chainset, res, return_state, summary_interval):
+    """The Results a fit returns: chain 1's table (states[1], gibbs.jl:788) and/or its Summary statistics from the device."""
+    if 1 in chainset.chains:
+        ch = chainset.chains[1]
+        if return_state:
+            res.state = new_table(ch.tot, ch.V, ch.R, dead=True)
+            ch.fetch(1, ch.tot, res.state)
+        if summary_interval is not None:
+            res.summary_device = device_summary(ch, res.burn_in, res.sampled, summary_interval)
+    return res
 
 
 class _Progress:
@@ -290,7 +330,7 @@ def _normalize_purge(purge_burn, nburn):
 
 def generate_samples(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1.0, nu=10, nburn=30000, nsamp=20000,
                      maxburn=50000, psrf_cutoff=1.2, x_transform=True, suppress_timer=False, num_chains=2, seed=None,
-                     purge_burn=None, device=None, _keep=None):
+                     purge_burn=None, device=None, _keep=None, return_state=True, summary_interval=None):
     """generate_samples! (gibbs.jl:897-1020): "traditional" scheme with PSRF-driven top-up rounds."""
     if nu < R:
         pass                                       # the reference constructs an ArgumentError without throwing it (901-902)
@@ -315,7 +355,7 @@ def generate_samples(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1
     p.done()
     tot_generated = nburn + nsamp
     stt = purge_burn if purge_burn is not None else nburn
-    res = return_psrf_VOI(cs, stt, nsamp)
+    res = return_psrf_VOI(cs, stt, nsamp, fetch_state=False)
     print("%d samples generated. Max PSRF XI: %.2f. Max PSRF Gamma: %.2f" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()), file=sys.stderr)
     while (res.rhatxi.max() > psrf_cutoff or res.rhatgamma.max() > psrf_cutoff) and tot_generated < (maxburn + nsamp):
         # we want to generate nburn more samples (gibbs.jl:963-974)
@@ -334,10 +374,11 @@ def generate_samples(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1
         A = (num2move + nburn) if num2move > 1 else nburn
         B = num2move
         tot_generated = tot_generated + A - B
-        res = return_psrf_VOI(cs, stt, nsamp)
+        res = return_psrf_VOI(cs, stt, nsamp, fetch_state=False)
         print("%d samples generated. Max PSRF XI: %.3f. Max PSRF Gamma: %.3f" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()), file=sys.stderr)
     print("R = %s nu=%s nburn= %d nsamp = %d" % (R, nu, nburn, nsamp))
     print("%d samples generated. Max PSRF XI: %.3f. Max PSRF Gamma: %.3f\n" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()))
+    res = _finish(cs, res, return_state, summary_interval)
     if _keep is None:
         cs.close()
     return res
@@ -345,7 +386,7 @@ def generate_samples(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1
 
 def generate_samples_dbl(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1.0, nu=10, mingen=10000,
                          maxgen=100000, psrf_cutoff=1.01, x_transform=True, suppress_timer=False, num_chains=2,
-                         seed=None, purge_burn=None, device=None):
+                         seed=None, purge_burn=None, device=None, return_state=True, summary_interval=None):
     """generate_samples_dbl! (gibbs.jl:1051-1198): "doubling generation" scheme."""
     if nu == R:
         print("Warning: ν==R may give poor accuracy. Consider increasing ν")
@@ -369,7 +410,7 @@ def generate_samples_dbl(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDel
     tot_generated = nburn + nsamp
     tot_samples = nsamp
     stt = purge_burn if purge_burn is not None else nburn
-    res = return_psrf_VOI(cs, stt, nsamp)
+    res = return_psrf_VOI(cs, stt, nsamp, fetch_state=False)
     print("%d samples generated. Max PSRF XI: %.3f. Max PSRF Gamma: %.3f" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()), file=sys.stderr)
 
     def _bad(r):
@@ -391,18 +432,21 @@ def generate_samples_dbl(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDel
         cs.run(num2move + 1, 0, tot_save, purge_burn, prog_freq, p.tick)           # run! :1176-1178
         p.done()
         tot_generated = tot_generated + mingen
-        res = return_psrf_VOI(cs, stt, nsamp)
+        res = return_psrf_VOI(cs, stt, nsamp, fetch_state=False)
         print("%d samples generated. Max PSRF XI: %.3f. Max PSRF Gamma: %.3f" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()), file=sys.stderr)
     print("\nR = %s nu=%s nburn= %d nsamp = %d\n" % (R, nu, nburn, nsamp))
     print("%d samples generated. Max PSRF XI: %.4f. Max PSRF Gamma: %.4f" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()))
+    res = _finish(cs, res, return_state, summary_interval)
     cs.close()
     return res
 
 
 def Fit(X, y, R, eta=1.01, V=30, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1.0, nu=10, nburn=30000, nsamples=20000,
         mingen=0, maxgen=0, psrf_cutoff=1.01, x_transform=True, suppress_timer=False, num_chains=2, seed=None,
-        purge_burn=None, filename="parameters.log", device=None):
-    """Fit! (gibbs.jl:725-751).  The `V` keyword is accepted and ignored, as in the reference."""
+        purge_burn=None, filename="parameters.log", device=None, return_state=True, summary_interval=None):
+    """Fit! (gibbs.jl:725-751).  The `V` keyword is accepted and ignored, as in the reference.
+    Extensions: summary_interval=95 computes Summary's statistics on the GPU (Results.summary_device);
+    return_state=False then leaves the (large) state table on the device and frees it."""
     seed = random.randrange(1, 55556) if seed is None else seed           # sample(1:55555) :739
     if _rank_world()[0] == 0 and filename:
         with open(filename, "w") as f:
@@ -417,7 +461,9 @@ def Fit(X, y, R, eta=1.01, V=30, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1.0, nu=
     if mingen > 0 and maxgen > 0:
         return generate_samples_dbl(X, y, R, eta=eta, zeta=zeta, iota=iota, aDelta=aDelta, bDelta=bDelta, nu=nu, mingen=mingen,
                                     maxgen=maxgen, psrf_cutoff=psrf_cutoff, x_transform=x_transform, suppress_timer=suppress_timer,
-                                    num_chains=num_chains, seed=seed, purge_burn=purge_burn, device=device)
+                                    num_chains=num_chains, seed=seed, purge_burn=purge_burn, device=device,
+                                    return_state=return_state, summary_interval=summary_interval)
     return generate_samples(X, y, R, eta=eta, zeta=zeta, iota=iota, aDelta=aDelta, bDelta=bDelta, nu=nu, nburn=nburn, nsamp=nsamples,
                             maxburn=nburn + nsamples, psrf_cutoff=psrf_cutoff, x_transform=x_transform,
-                            suppress_timer=suppress_timer, num_chains=num_chains, seed=seed, purge_burn=purge_burn, device=device)
+                            suppress_timer=suppress_timer, num_chains=num_chains, seed=seed, purge_burn=purge_burn, device=device,
+                            return_state=return_state, summary_interval=summary_interval)

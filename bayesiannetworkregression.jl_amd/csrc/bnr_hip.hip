@@ -1026,6 +1026,37 @@ int bnr_chain_rhat_stats(bnr_chain *c, int32_t first_row, int32_t nsamp, double 
     return check_launch("k_rhat_stats");
 }
 
+// Summary(results) on the device (gibbs.jl:1214-1250): posterior mean and two order statistics of every gamma_e over rows
+// first_row .. first_row+nsamp-1, and the mean of every xi_v.  3q + V doubles cross PCIe instead of the gamma trace.
+int bnr_chain_summary(bnr_chain *c, int32_t first_row, int32_t nsamp, int32_t k_lo, int32_t k_hi,
+                      double *mean_gamma, double *lower, double *upper, double *prob_xi)
+{
+    if (!c || !mean_gamma || !lower || !upper || !prob_xi) return fail(BNR_ERR_BAD_ARG, "NULL argument");
+    if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");
+    const bnr_dev &d = c->d;
+    if (first_row < 1 || nsamp < 1 || first_row + nsamp - 1 > d.tot) return fail(BNR_ERR_BAD_ARG, "row window outside the table");
+    if (k_lo < 1 || k_lo > nsamp || k_hi < 1 || k_hi > nsamp) return fail(BNR_ERR_BAD_ARG, "order statistics must be between 1 and nsamp");
+    HIPCHK(hipSetDevice(c->device));
+    const int np = d.q + d.V;
+    double *buf = nullptr, *out = nullptr;
+    HIPCHK(hipMalloc((void **)&buf, sizeof(double) * (size_t)np * nsamp));
+    if (hipMalloc((void **)&out, sizeof(double) * 3 * (size_t)np) != hipSuccess) { hipFree(buf); return fail(BNR_ERR_HIP, "hipMalloc failed"); }
+    dim3 block(32, 8);
+    hipLaunchKernelGGL(k_fetch_cols, dim3((d.q + 31) / 32, (nsamp + 31) / 32), block, 0, c->x.stream, (const double *)d.trace, d.rowlen, d.o_gamma, d.q, first_row - 1, nsamp, buf);
+    hipLaunchKernelGGL(k_fetch_cols, dim3((d.V + 31) / 32, (nsamp + 31) / 32), block, 0, c->x.stream, (const double *)d.trace, d.rowlen, d.o_xi, d.V, first_row - 1, nsamp, buf + (size_t)d.q * nsamp);
+    hipLaunchKernelGGL(k_summary, dim3(np), dim3(256), 0, c->x.stream, (const double *)buf, nsamp, d.q, k_lo, k_hi, out, out + np, out + 2 * (size_t)np);
+    std::vector<double> host(3 * (size_t)np);
+    hipError_t e = hipMemcpyAsync(host.data(), out, sizeof(double) * host.size(), hipMemcpyDeviceToHost, c->x.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->x.stream);
+    hipFree(buf); hipFree(out);
+    if (e != hipSuccess) return fail(BNR_ERR_HIP, std::string("summary: ") + hipGetErrorString(e));
+    memcpy(mean_gamma, host.data(), sizeof(double) * d.q);
+    memcpy(prob_xi, host.data() + d.q, sizeof(double) * d.V);
+    memcpy(lower, host.data() + np, sizeof(double) * d.q);
+    memcpy(upper, host.data() + 2 * (size_t)np, sizeof(double) * d.q);
+    return check_launch("k_summary");
+}
+
 int bnr_rhat_from_stats(const double *stats, int32_t nchains, int32_t nparams, int32_t nsamp, double *rhat)
 {
     if (!stats || !rhat || nchains < 1 || nparams < 1) return fail(BNR_ERR_BAD_ARG, "bad argument");

@@ -412,20 +412,27 @@ __global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int w
 // blockIdx.y = K slice across workgroups (split-K partials, summed by k_gram_reduce).
 typedef double bnr_d4 __attribute__((ext_vector_type(4)));
 typedef double bnr_d2 __attribute__((ext_vector_type(2)));
-#define BNR_GRAM_KB 8                 // columns of X per staged batch (2 MFMA k-steps)
-#define BNR_GRAM_CS 80                // LDS column stride in doubles: 64 rows + 16 pad -> conflict-free ds_read_b64 fragments
+#define BNR_GRAM_KB 16                // columns of X per staged batch (4 MFMA k-steps): one barrier per 16 MFMAs of a wave
 
-// LDS-staged, double-buffered K loop.  Per K-group (4 waves = 256 threads) and batch: the j-side panel X[j-rows, 8 cols]
-// and the S-scaled i-side panel are loaded one batch ahead with coalesced 16-byte global loads (registers), written to
-// LDS [col][row] with a padded column stride, and read back as MFMA fragments with ds_read_b64.
-// KG = K-groups per workgroup.  KG = 4: 1024 threads, one workgroup per CU.  KG = 2: 512 threads and 64 KiB of LDS, TWO
-// workgroups per CU, so that the prologue (first loads), the K-group reduction and the store of one workgroup overlap
-// with the MFMA loop of its neighbour when a launch runs for several rounds (lockstep groups).
+#ifndef BNR_GRAM_EXP
+#define BNR_GRAM_EXP 0        // timing experiments only (tools/gram_experiments.sh): 1 no S scaling, 2 no global loads in the loop, 3 both
+#endif
+
+// LDS-staged K loop.  Per K-group (4 waves = 256 threads) and batch of 16 columns: the j-side panel X[j-rows, 16 cols] and
+// the S-scaled i-side panel travel global -> registers (16-byte loads, issued one whole batch ahead) -> LDS image
+// [col][64 rows], and come back as MFMA fragments with ds_read_b64.  The image is unpadded; odd columns store their two
+// 16-row halves swapped (row ^ 16), which puts the four columns of a fragment read on disjoint banks (the same
+// conflict-free pattern a padded stride of 80 gives, in 20 % less LDS: 32 KiB per K-group, two workgroups per CU).
+// One register set, two LDS buffers: after the barrier a wave first writes batch b+1 (loaded during batch b-1), re-issues
+// the loads of batch b+2, then computes batch b.
+// KG = K-groups per workgroup.  KG = 2: 512 threads and 64 KiB of LDS, TWO workgroups per CU, so that the prologue (first
+// loads), the K-group reduction and the store of one workgroup overlap with the MFMA loop of its neighbour when a launch
+// runs for several rounds (lockstep groups).  KG = 4: 1024 threads, one workgroup per CU.
 // Grid (1-D) = round_up(tasks, 8) x chains.  Workgroup id -> XCD label id % 8 (round-robin dispatch), and within one
 // XCD's sequence the chains of a lockstep group are innermost: the 8 (or C) workgroups that need the same panels of X
 // (same tile, same K slice, different S) run next to each other on the same XCD and share them through its L2.
 template <class SRC, int KG>
-__global__ __launch_bounds__(KG * 256) void k_gram(const SRC chain_src, int s, int nchains)
+__global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, int s, int nchains)
 {
     const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
     const int gchain = gr % nchains, gslot = (gr / nchains) * 8 + gx;      // gslot: position in the one-chain task map
@@ -433,17 +440,12 @@ __global__ __launch_bounds__(KG * 256) void k_gram(const SRC chain_src, int s, i
     __shared__ double sred[KG * BNR_GT * BNR_GT];     // staging buffers during the loop, then the K-group reduction
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     const double *Sp = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
-    // workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD); the host-built map gives the
-    // workgroups of one XCD the same K slice, so that slice of X (~3 MB) stays in that XCD's 4 MB L2.  Speed only.
 #ifdef BNR_STAMPS
 #define BNR_GSTAMP(slot) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 251)) { int o_ = 400 + 8 * (blockIdx.x == 0 ? 0 : (blockIdx.x == 100 ? 1 : 2)) + (slot); cd.dbg[o_] = __builtin_amdgcn_s_memtime(); cd.dbg[o_ + 4] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define BNR_GSTAMP(slot) do { } while (0)
 #endif
     BNR_GSTAMP(0);
-#ifdef BNR_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < 256) { cd.dbg[512 + blockIdx.x] = __builtin_amdgcn_s_memrealtime(); unsigned xcc = __builtin_amdgcn_s_getreg((20 | (0 << 6) | (3 << 11))); unsigned hwid = __builtin_amdgcn_s_getreg((4 | (0 << 6) | (31 << 11))); cd.dbg[256 + blockIdx.x] = ((unsigned long long)xcc << 32) | hwid; }
-#endif
     // the task map's extent is padded to a multiple of 8 so that id % 8 labels the XCD
     if (gslot >= cd.ksplit * (cd.ntile * (cd.ntile + 1) / 2)) return;
     const int task = cd.gmap[gslot];
@@ -453,81 +455,79 @@ __global__ __launch_bounds__(KG * 256) void k_gram(const SRC chain_src, int s, i
     int tj = t - ti * (ti + 1) / 2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kg = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
-    const int kchunk = cd.q_pad / cd.ksplit;          // multiple of 32 (host guarantees)
+    const int kchunk = cd.q_pad / cd.ksplit;          // multiple of 8 KG (host guarantees)
     const int ksub = kchunk / KG;                     // multiple of 8
     const int eb = ks * kchunk + kg * ksub;
-    const int nbatch = ksub / BNR_GRAM_KB;
+    const int nfull = ksub / BNR_GRAM_KB;             // whole batches; ksub % 16 == 8 leaves one half batch
+    const bool half = (ksub % BNR_GRAM_KB) != 0;
+    const int nbatch = nfull + (half ? 1 : 0);
     const size_t ld = cd.n_pad;
     const int li = lane & 15, lk = lane >> 4;
-    // staging: this thread moves rows (2 rp, 2 rp + 1) of column c of both panels.  Addresses = wave-uniform base of the
-    // batch (SGPRs, advanced by scalar adds) + a per-lane offset that never changes: no vector address arithmetic in the loop
+    // staging: this thread moves rows (2 rp, 2 rp + 1) of columns c and c + 8 of both panels.  Addresses = wave-uniform base
+    // of the batch (SGPRs, advanced by scalar adds) + a per-lane offset that never changes
     const int tg = threadIdx.x & 255, c = tg >> 5, rp = tg & 31;
     const size_t offI = (size_t)(ti * BNR_GT + 2 * rp) + (size_t)c * ld, offJ = (size_t)(tj * BNR_GT + 2 * rp) + (size_t)c * ld;
     const double *xb = cd.X + (size_t)eb * ld;                         // uniform: first column of this K-group
     const double *sb = Sp + eb;                                        // uniform (columns >= q hold zeros in X: any finite S is fine)
     const int smax = cd.q - 1 - eb;                                    // clamp for the S index
-    const int PANEL = BNR_GRAM_KB * BNR_GRAM_CS;                       // doubles per panel
-    double *stg = sred + (size_t)kg * (4 * PANEL);                     // [buf][I|J][col][row]
-    const int woff = c * BNR_GRAM_CS + 2 * rp;
+    const int PANEL = BNR_GRAM_KB * BNR_GT;                            // doubles per panel (16 columns x 64 rows)
+    double *stg = sred + (size_t)kg * (4 * PANEL);                     // [buf][I|J][col][row ^ swizzle]
+    const int woff = c * BNR_GT + ((2 * rp) ^ ((c & 1) << 4));         // columns c and c + 8 have the same parity
+    // fragment rows of this lane: column 4 k2 + lk has parity lk & 1
+    const int sw = (lk & 1) << 4;
+    const int ra0 = (wj * 32 + li) ^ sw, ra1 = (wj * 32 + 16 + li) ^ sw, rb0 = (wi * 32 + li) ^ sw, rb1 = (wi * 32 + 16 + li) ^ sw;
     bnr_d4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};   // c[jt][it]
-    // register prefetch two batches deep, loop unrolled by two so that the register sets alternate without moves
-    bnr_d2 riA, rjA, riB, rjB;
-    double svA, svB;
-#ifndef BNR_GRAM_EXP
-#define BNR_GRAM_EXP 0        // timing experiments only (tools/gram_experiments.sh): 1 no S scaling, 2 no global loads in the loop, 3 both
-#endif
-#define BNR_GRAM_LOAD(RI, RJ, SV, BIDX)                                                                   \
+    bnr_d2 ri0, ri1, rj0, rj1;
+    double sv0, sv1;
+#define BNR_GRAM_LOAD(BIDX)                                                                               \
     do {                                                                                                  \
-        const double *cb_ = xb + (size_t)(((BNR_GRAM_EXP & 2) && (BIDX) > 2) ? 0 : (BIDX)) * (BNR_GRAM_KB * ld); \
+        const bool keep_ = (BNR_GRAM_EXP & 2) && (BIDX) > 1;                                              \
+        const double *cb_ = xb + (size_t)(keep_ ? 0 : (BIDX)) * (BNR_GRAM_KB * ld);                       \
         int si_ = (BIDX) * BNR_GRAM_KB + c;                                                               \
-        if (!(BNR_GRAM_EXP & 1)) SV = sb[si_ < smax ? si_ : smax]; else SV = 1.0;                         \
-        if (!(BNR_GRAM_EXP & 2) || (BIDX) <= 2) {                                                         \
-            RI = *(const bnr_d2 *)(cb_ + offI);                                                           \
-            RJ = *(const bnr_d2 *)(cb_ + offJ);                                                           \
+        if (!(BNR_GRAM_EXP & 1)) { sv0 = sb[si_ < smax ? si_ : smax]; sv1 = sb[si_ + 8 < smax ? si_ + 8 : smax]; } \
+        else { sv0 = 1.0; sv1 = 1.0; }                                                                    \
+        if (!keep_) {                                                                                     \
+            ri0 = *(const bnr_d2 *)(cb_ + offI); ri1 = *(const bnr_d2 *)(cb_ + offI + 8 * ld);            \
+            rj0 = *(const bnr_d2 *)(cb_ + offJ); rj1 = *(const bnr_d2 *)(cb_ + offJ + 8 * ld);            \
         }                                                                                                 \
     } while (0)
-#define BNR_GRAM_STORE(RI, RJ, SV, BUF)                                                                   \
+#define BNR_GRAM_STORE(BUF)                                                                               \
     do {                                                                                                  \
         double *nx_ = stg + (size_t)(BUF) * (2 * PANEL);                                                  \
-        *(bnr_d2 *)(nx_ + woff) = (BNR_GRAM_EXP & 1) ? RI : RI * SV;                                      \
-        *(bnr_d2 *)(nx_ + PANEL + woff) = RJ;                                                             \
+        *(bnr_d2 *)(nx_ + woff) = (BNR_GRAM_EXP & 1) ? ri0 : ri0 * sv0;                                   \
+        *(bnr_d2 *)(nx_ + 8 * BNR_GT + woff) = (BNR_GRAM_EXP & 1) ? ri1 : ri1 * sv1;                      \
+        *(bnr_d2 *)(nx_ + PANEL + woff) = rj0;                                                            \
+        *(bnr_d2 *)(nx_ + PANEL + 8 * BNR_GT + woff) = rj1;                                               \
     } while (0)
-#define BNR_GRAM_COMPUTE(BUF)                                                                             \
+#define BNR_GRAM_COMPUTE(BUF, NK2)                                                                        \
     do {                                                                                                  \
         const double *bufI = stg + (size_t)(BUF) * (2 * PANEL), *bufJ = bufI + PANEL;                     \
-        _Pragma("unroll") for (int k2 = 0; k2 < BNR_GRAM_KB / 4; ++k2) {                                  \
-            const int kk = (4 * k2 + lk) * BNR_GRAM_CS;                                                   \
-            double a0 = bufJ[kk + wj * 32 + li], a1 = bufJ[kk + wj * 32 + 16 + li];                       \
-            double b0 = bufI[kk + wi * 32 + li], b1 = bufI[kk + wi * 32 + 16 + li];                       \
+        _Pragma("unroll") for (int k2 = 0; k2 < (NK2); ++k2) {                                            \
+            const int kk = (4 * k2 + lk) * BNR_GT;                                                        \
+            double a0 = bufJ[kk + ra0], a1 = bufJ[kk + ra1];                                              \
+            double b0 = bufI[kk + rb0], b1 = bufI[kk + rb1];                                              \
             c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);                             \
             c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);                             \
             c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);                             \
             c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);                             \
         }                                                                                                 \
     } while (0)
-    // nbatch is even or odd; batches beyond the end read the zero-padded tail of X (q_pad has one spare batch per slice? no:
-    // the host pads q_pad so that loads up to batch nbatch+1 of the LAST K-group stay inside the allocation)
-    BNR_GRAM_LOAD(riA, rjA, svA, 0);
-    BNR_GRAM_STORE(riA, rjA, svA, 0);
-    BNR_GRAM_LOAD(riA, rjA, svA, 1);
-    BNR_GRAM_LOAD(riB, rjB, svB, 2);
+    // batches past the end of the slice read the following columns or the zero-padded tail of X (the host allocates
+    // q_pad + 64 columns); they are stored but never used by a compute step
+    BNR_GRAM_LOAD(0);
+    BNR_GRAM_STORE(0);
+    BNR_GRAM_LOAD(1);
     __syncthreads();
     BNR_GSTAMP(1);
-    int b = 0;
-    for (; b + 1 < nbatch; b += 2) {
-        BNR_GRAM_COMPUTE(0);
-        BNR_GRAM_STORE(riA, rjA, svA, 1);          // batch b+1
-        BNR_GRAM_LOAD(riA, rjA, svA, b + 3);
-        __syncthreads();
-        BNR_GRAM_COMPUTE(1);
-        BNR_GRAM_STORE(riB, rjB, svB, 0);          // batch b+2
-        BNR_GRAM_LOAD(riB, rjB, svB, b + 4);
+    for (int b = 0; b < nfull; ++b) {
+        BNR_GRAM_STORE((b + 1) & 1);               // batch b+1, loaded a whole batch ago
+        BNR_GRAM_LOAD(b + 2);
+        BNR_GRAM_COMPUTE(b & 1, 4);
         __syncthreads();
     }
-    if (b < nbatch) { BNR_GRAM_COMPUTE(0); __syncthreads(); }
+    if (half) { BNR_GRAM_COMPUTE(nfull & 1, 2); __syncthreads(); }
+    (void)nbatch;
     BNR_GSTAMP(2);
-    const int i0 = 0, j0 = 0;
-    (void)i0; (void)j0;
     // tile element (i,j) lives at [j*64 + i]; this lane: j = wj*32 + jt*16 + (lane>>4) + 4 r, i = wi*32 + it*16 + (lane&15)
     double *mine = sred + (size_t)kg * (BNR_GT * BNR_GT);
     const int jb = wj * 32 + (lane >> 4), ib = wi * 32 + (lane & 15);
@@ -546,9 +546,6 @@ __global__ __launch_bounds__(KG * 256) void k_gram(const SRC chain_src, int s, i
         else out[idx] = sred[idx] + sred[BNR_GT * BNR_GT + idx];
     }
     BNR_GSTAMP(3);
-#ifdef BNR_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < 256) cd.dbg[768 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-#endif
 }
 
 // E = extended matrix of the factorization, (2 n_pad + 32) x n_pad, column-major, leading dimension ldE:
@@ -1430,5 +1427,85 @@ __global__ void k_rhat_stats(bnr_dev cd, int first, int nsamp, double *out)
         for (int r = 0; r < h; ++r) { double d = cd.trace[(size_t)(r0 + r) * cd.rowlen + off] - mean; v += d * d; }
         out[(size_t)(2 * half) * np + p] = mean;
         out[(size_t)(2 * half + 1) * np + p] = v / (h - 1);
+    }
+}
+
+// ===================================================================================== k_summary
+// Device side of Summary(results) (gibbs.jl:1214-1250): per edge e the posterior mean of gamma_e over the sampled rows and
+// two order statistics (the k_lo-th and k_hi-th smallest, 1-based: the reference indexes the sorted column at
+// round(nsamp*lower) and round(nsamp*upper)); per node the mean of xi.  Only 3q + V numbers leave the GPU instead of the
+// nsamp x q gamma trace.
+// `buf` holds the window transposed by k_fetch_cols: column p (gamma_0..gamma_{q-1}, then xi_0..xi_{V-1}) is contiguous,
+// nsamp doubles.  One workgroup of 256 threads per column.  Exact selection by MSD radix counting on the order-preserving
+// 64-bit image of the doubles: 6 passes (11,11,11,11,11,9 bits) of a 2048-bin LDS histogram per statistic.
+__device__ __forceinline__ unsigned long long bnr_key_of(double v)
+{
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double bnr_double_of(unsigned long long k)
+{
+    unsigned long long u = (k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+__global__ __launch_bounds__(256) void k_summary(const double *buf, int nsamp, int q, int k_lo, int k_hi, double *mean, double *lo, double *hi)
+{
+    __shared__ unsigned int hist[2048];
+    __shared__ unsigned int part[256];
+    __shared__ double red[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_k;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const double *col = buf + (size_t)p * nsamp;
+    // mean: fixed summation order (thread-strided partial sums, then a tree)
+    double acc = 0.0;
+    for (int i = tid; i < nsamp; i += 256) acc += col[i];
+    red[tid] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (tid < w) red[tid] += red[tid + w]; __syncthreads(); }
+    if (tid == 0) mean[p] = red[0] / nsamp;
+    if (p >= q) return;                                  // xi columns: mean only
+    for (int stat = 0; stat < 2; ++stat) {
+        if (tid == 0) { s_prefix = 0ull; s_k = stat == 0 ? k_lo : k_hi; }
+        __syncthreads();
+        int shift = 64;
+        for (int pass = 0; pass < 6; ++pass) {
+            const int bits = pass < 5 ? 11 : 9;
+            shift -= bits;
+            const unsigned long long prefix = s_prefix;
+            const unsigned long long himask = shift + bits >= 64 ? 0ull : (~0ull << (shift + bits));
+            for (int b = tid; b < 2048; b += 256) hist[b] = 0u;
+            __syncthreads();
+            for (int i = tid; i < nsamp; i += 256) {
+                unsigned long long key = bnr_key_of(col[i]);
+                if ((key & himask) == prefix) atomicAdd(&hist[(unsigned int)((key >> shift) & ((1u << bits) - 1u))], 1u);
+            }
+            __syncthreads();
+            // find the bin that holds the s_k-th smallest of the surviving elements: 8 bins per thread, scan over threads
+            unsigned int mysum = 0;
+            for (int b = 0; b < 8; ++b) mysum += hist[tid * 8 + b];
+            part[tid] = mysum;
+            __syncthreads();
+            for (int off = 1; off < 256; off <<= 1) {
+                unsigned int v = tid >= off ? part[tid - off] : 0u;
+                __syncthreads();
+                part[tid] += v;
+                __syncthreads();
+            }
+            const unsigned int incl = part[tid], excl = incl - mysum;
+            const int k = s_k;
+            __syncthreads();
+            if ((unsigned int)k > excl && (unsigned int)k <= incl) {       // exactly one thread
+                unsigned int run = excl;
+                for (int b = 0; b < 8; ++b) {
+                    unsigned int cnt = hist[tid * 8 + b];
+                    if ((unsigned int)k <= run + cnt) { s_prefix = prefix | ((unsigned long long)(tid * 8 + b) << shift); s_k = k - (int)run; break; }
+                    run += cnt;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) (stat == 0 ? lo : hi)[p] = bnr_double_of(s_prefix);
+        __syncthreads();
     }
 }

@@ -140,6 +140,13 @@ int bnr_chain_resize(bnr_chain *chain, int32_t new_tot);
  * [mean_h0(q+V) | var_h0(q+V) | mean_h1(q+V) | var_h1(q+V)].  This is the per-chain message that is
  * all-gathered across ranks (RCCL via torch.distributed in the host layer). */
 int bnr_chain_rhat_stats(bnr_chain *chain, int32_t first_row, int32_t nsamp, double *stats);
+/* Summary(results) (gibbs.jl:1214-1250) computed on the device over rows first_row .. first_row+nsamp-1 of this chain's
+ * table: mean_gamma[q] = posterior mean of every edge coefficient, lower[q] / upper[q] = the k_lo-th / k_hi-th smallest
+ * sample of every edge (1-based; the reference takes sort(gamma)[round(nsamp*lower_bound)] and [round(nsamp*upper_bound)]),
+ * prob_xi[V] = posterior mean of xi.  Exact selection; only 3q + V doubles cross PCIe.  Rounding to `digits` is the caller's. */
+int bnr_chain_summary(bnr_chain *chain, int32_t first_row, int32_t nsamp, int32_t k_lo, int32_t k_hi,
+                      double *mean_gamma, double *lower, double *upper, double *prob_xi);
+
 /* second half: combine nchains messages (host arrays, chain-major) into Rhat per parameter.  Pure host code.
  * rhat: q+V doubles (gamma first, then xi).  Replaces convergence.jl:49-61. */
 int bnr_rhat_from_stats(const double *stats, int32_t nchains, int32_t nparams, int32_t nsamp, double *rhat);

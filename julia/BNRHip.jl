@@ -50,6 +50,16 @@ end
 
 init_prior!(ch::Chain) = check(ccall((:bnr_chain_init_prior, LIB), Cint, (Ptr{Cvoid},), ch.h))
 
+# Summary statistics on the device (gibbs.jl:1214-1250): (mean γ, lower, upper, P(ξ=1)); ranks are 1-based positions in the sorted sample
+function summary_stats(ch::Chain, nburn, nsamp; interval=95)
+    lb = (100 - interval) / 200
+    klo, khi = Int(round(nsamp * lb)), Int(round(nsamp * (1 - lb)))
+    m, lo, hi, p = zeros(ch.q), zeros(ch.q), zeros(ch.q), zeros(ch.V)
+    check(ccall((:bnr_chain_summary, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+        ch.h, nburn + 1, nsamp, klo, khi, m, lo, hi, p))
+    m, lo, hi, p
+end
+
 # lockstep group: the chains of one fit that share a GPU advance together (replaces the pmap over chains, gibbs.jl:946-948)
 mutable struct Group
     h::Ptr{Cvoid}

@@ -355,6 +355,61 @@ def test_generate_samples_end_to_end(gpu, test1, tmp_path):
     assert r3.burn_in == 10 and r3.sampled == 20 and r3.state["gamma"].shape[0] == 30
 
 
+def test_device_summary_equals_host_summary(gpu, test1):
+    """bnr_chain_summary (Summary on the device, gibbs.jl:1214-1250): the posterior means agree with the host to rounding,
+    the order statistics are EXACTLY the entries of the sorted trace the reference indexes -- also with ties, negative
+    values, +-0 and a window that does not start at row 1 -- and Summary() prints the same table from either source."""
+    X, y = test1
+    tot = 120
+    ch = bnr_amd.Chain(X, y, 5, tot, 2024, 1)
+    ch.init_prior()
+    ch.run(2, tot, tot)
+    t = ch.fetch()
+    # plant ties / signed zeros / extreme values in a few gamma columns (the kernel only reads the table)
+    t["gamma"][40:, 0, 0] = 0.25
+    t["gamma"][40:80, 1, 0] = -0.0
+    t["gamma"][80:, 1, 0] = 0.0
+    t["gamma"][40:, 2, 0] = np.where(np.arange(80) % 2 == 0, -1e300, 1e-300)      # extreme exponents (selection works on the bit image)
+    t["gamma"][40:, 3, 0] = -np.abs(t["gamma"][40:, 3, 0])
+    ch.load(t)
+    for nburn, nsamp, interval in ((40, 80, 95), (0, 120, 95), (17, 101, 50), (60, 60, 90)):
+        g = t["gamma"][nburn:nburn + nsamp, :, 0]
+        gs = np.sort(g, axis=0)
+        lw, hi = bnr_amd.api._summary_ranks(nsamp, interval)
+        dev = bnr_amd.device_summary(ch, nburn, nsamp, interval)
+        assert np.array_equal(dev["lower_bound"], gs[lw - 1]) and np.array_equal(dev["upper_bound"], gs[hi - 1])
+        assert np.all(np.abs(dev["estimate"] - g.mean(axis=0)) <= 1e-13 * np.abs(g).mean(axis=0))     # summation order only
+        assert np.allclose(dev["probability"], t["xi"][nburn:nburn + nsamp, :, 0].mean(axis=0), rtol=1e-13)
+        full = bnr_amd.new_table(tot, 19, 5, dead=True)
+        ch.fetch(1, tot, full)
+        host = bnr_amd.Summary(bnr_amd.Results(full, None, None, nburn, nsamp), interval)
+        devs = bnr_amd.Summary(bnr_amd.Results(None, None, None, nburn, nsamp, dev), interval)
+        for k in ("lower_bound", "upper_bound"):
+            assert np.array_equal(host.edge_coef[k], devs.edge_coef[k]), k
+        # the means are sums in a different order: equal to rounding, so the 3-digit table can differ by one unit in the
+        # last printed digit only where a mean sits on a rounding boundary (and not at all for moderate magnitudes)
+        ok = np.abs(host.edge_coef["estimate"]) < 1e6
+        assert np.allclose(host.edge_coef["estimate"][ok], devs.edge_coef["estimate"][ok], rtol=0, atol=1.0001e-3)
+        assert np.mean(host.edge_coef["estimate"][ok] == devs.edge_coef["estimate"][ok]) > 0.98
+        assert np.allclose(host.prob_nodes["probability"], devs.prob_nodes["probability"], rtol=0, atol=1.0001e-3)
+    with pytest.raises(IndexError):
+        bnr_amd.device_summary(ch, 60, 60, 99)                      # round(60 * 0.005) = 0: the reference stops with a BoundsError
+    with pytest.raises(bnr_amd.BnrError):
+        ch.summary(1, tot, 0, 5)
+    with pytest.raises(bnr_amd.BnrError):
+        ch.summary(100, 50, 1, 5)
+    ch.close()
+    # through the fit: Results without the state table, Summary from the device statistics
+    r = bnr_amd.Fit(X, y, 5, nburn=30, nsamples=40, psrf_cutoff=50.0, x_transform=False, suppress_timer=True, num_chains=2,
+                    seed=77, filename=None, return_state=False, summary_interval=95)
+    r2 = bnr_amd.Fit(X, y, 5, nburn=30, nsamples=40, psrf_cutoff=50.0, x_transform=False, suppress_timer=True, num_chains=2,
+                     seed=77, filename=None)
+    assert r.state is None and r.summary_device is not None and r2.summary_device is None
+    sa, sb = bnr_amd.Summary(r), bnr_amd.Summary(r2)
+    assert np.array_equal(sa.edge_coef["lower_bound"], sb.edge_coef["lower_bound"]) and np.array_equal(sa.edge_coef["upper_bound"], sb.edge_coef["upper_bound"])
+    assert np.allclose(sa.edge_coef["estimate"], sb.edge_coef["estimate"], rtol=0, atol=1.0001e-3)
+
+
 def test_bad_arguments_are_reported(gpu):
     X, y, _ = bnr_amd.make_synthetic(8, 4, 2, seed=1)
     with pytest.raises(bnr_amd.BnrError) as e:
