@@ -63,19 +63,34 @@ struct bnr_dev {
 // group: a device array indexed by blockIdx.z (one more scalar load, paid once per launch for all members).
 // get_x(): kernels whose grid is (chain, workgroup) -- chain fastest, so that the workgroups with the same role of all
 // members are dispatched together (k_chol_step: every member's panel workgroups before anybody's update workgroups).
+// A descriptor read from memory carries GENERIC pointers: the compiler would emit flat_load/flat_store for everything
+// reached through them, and flat operations also count on lgkmcnt -- every wait for an LDS read would then wait for
+// the global loads in flight as well (measured in k_gram: the staging loads' latency exposed once per batch).  The
+// descriptor's pointers are therefore passed through an address-space cast, after which they are known to be global
+// (what the compiler infers by itself for a by-value kernel argument).
+// (through an integer: a plain generic -> global -> generic cast pair is folded away before the inference pass runs)
+#define BNR_GLOBAL_PTR(member) d.member = (decltype(d.member))(__attribute__((address_space(1))) void *)(unsigned long long)(d.member)
+__device__ __forceinline__ bnr_dev bnr_globalized(const bnr_dev *src)
+{
+    bnr_dev d = *src;
+    BNR_GLOBAL_PTR(X); BNR_GLOBAL_PTR(y); BNR_GLOBAL_PTR(ek); BNR_GLOBAL_PTR(el); BNR_GLOBAL_PTR(trace); BNR_GLOBAL_PTR(plan);
+    BNR_GLOBAL_PTR(pbase); BNR_GLOBAL_PTR(Wbuf); BNR_GLOBAL_PTR(sz); BNR_GLOBAL_PTR(PW); BNR_GLOBAL_PTR(PA); BNR_GLOBAL_PTR(PG);
+    BNR_GLOBAL_PTR(Gpart); BNR_GLOBAL_PTR(E); BNR_GLOBAL_PTR(gmap); BNR_GLOBAL_PTR(a3); BNR_GLOBAL_PTR(xw); BNR_GLOBAL_PTR(a4);
+    BNR_GLOBAL_PTR(res); BNR_GLOBAL_PTR(xg); BNR_GLOBAL_PTR(bw); BNR_GLOBAL_PTR(wv); BNR_GLOBAL_PTR(scal); BNR_GLOBAL_PTR(Minv);
+    BNR_GLOBAL_PTR(Psum); BNR_GLOBAL_PTR(counters); BNR_GLOBAL_PTR(dbg); BNR_GLOBAL_PTR(stamp);
+    return d;
+}
 struct bnr_one {
     bnr_dev d;
     __device__ __forceinline__ const bnr_dev &get() const { return d; }
     __device__ __forceinline__ const bnr_dev &get_x() const { return d; }
     __device__ __forceinline__ const bnr_dev &at(int) const { return d; }
-    static constexpr bool many = false;
 };
 struct bnr_many {
     const bnr_dev *p;
-    __device__ __forceinline__ const bnr_dev &get() const { return p[blockIdx.z]; }
-    __device__ __forceinline__ const bnr_dev &get_x() const { return p[blockIdx.x]; }
-    __device__ __forceinline__ const bnr_dev &at(int c) const { return p[c]; }
-    static constexpr bool many = true;
+    __device__ __forceinline__ bnr_dev get() const { return bnr_globalized(p + blockIdx.z); }
+    __device__ __forceinline__ bnr_dev get_x() const { return bnr_globalized(p + blockIdx.x); }
+    __device__ __forceinline__ bnr_dev at(int c) const { return bnr_globalized(p + c); }
 };
 
 enum { ROW_TAU2 = 0, ROW_THETA = 1, ROW_DELTA = 2, ROW_MU = 3 };

@@ -102,8 +102,8 @@ def main():
     K, W, C = a.steps, a.warmup, a.chains_per_gpu
     tot = W + K + min(K, 200) + 1
     chains = []
-    for lc in range(C):
-        cid = rank * C + lc + 1                                   # chain c uses stream seed + c (gibbs.jl:928)
+    ids = [c for c in range(1, world * C + 1) if (c - 1) % world == rank]     # round-robin over ranks, as api.local_chain_ids
+    for cid in ids:                                               # chain c uses stream seed + c (gibbs.jl:928)
         ch = bnr_amd.Chain(X, y, R, tot, a.seed, cid, device=local_rank) if not chains else bnr_amd.Chain.like(chains[0], a.seed, cid, tot)
         ch.init_prior()
         chains.append(ch)
@@ -159,7 +159,7 @@ def main():
         runner.close()
         runner = None
         Ks = min(K, 1000)
-        solo = bnr_amd.Chain.like(chains[0], a.seed, rank * C + 1, Ks + 50)
+        solo = bnr_amd.Chain.like(chains[0], a.seed, ids[0], Ks + 50)
         solo.init_prior()
         solo.run(2, 49, 49)
         torch.cuda.synchronize()
@@ -176,7 +176,7 @@ def main():
 
     # convergence check over all chains of the job: RCCL all-gather of the per-chain split-Rhat messages
     nsamp = K
-    local = {rank * C + lc + 1: ch.rhat_stats(W + 2, nsamp) for lc, ch in enumerate(chains)}
+    local = {cid: ch.rhat_stats(W + 2, nsamp) for cid, ch in zip(ids, chains)}
     if dist:
         stats = bnr_amd.allgather_stats(local, world * C)
     else:
