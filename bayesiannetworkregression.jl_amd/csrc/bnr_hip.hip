@@ -390,7 +390,7 @@ static int check_launch(const char *what)
 static void launch_node(bnr_exec &x, int s, int mode)
 { BNR_LAUNCH(k_node, dim3(x.shape->V, 1, x.nb), dim3(64), 64 * (2 * x.shape->R + 1) * sizeof(double), x.stream, x, s, mode); }
 static void launch_xpass(bnr_exec &x, int s, int which)
-{ BNR_LAUNCH(k_xpass, dim3(x.shape->nblk_x, 1, x.nb), dim3(256), 3 * x.shape->chunk_x * sizeof(double), x.stream, x, s, which); }
+{ BNR_LAUNCH(k_xpass, dim3(round_up(x.shape->nblk_x, 8) * x.nb), dim3(256), 3 * x.shape->chunk_x * sizeof(double), x.stream, x, s, which, x.nb); }
 static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
 {
     const bnr_dev &d = *x.shape;
@@ -430,7 +430,7 @@ static void launch_solve(bnr_exec &x)
 static void launch_backproj(bnr_exec &x, int s, int flags)
 {
     size_t lds = std::max<size_t>(x.shape->n_pad + 64, (size_t)(3 * x.shape->R + 1) * 33) * sizeof(double);
-    BNR_LAUNCH(k_backproj, dim3(x.shape->nblk_bp, 1, x.nb), dim3(256), lds, x.stream, x, s, flags);
+    BNR_LAUNCH(k_backproj, dim3(round_up(x.shape->nblk_bp, 8) * x.nb), dim3(256), lds, x.stream, x, s, flags, x.nb);
 }
 static void launch_tail(bnr_exec &x, int s, int mask, int xg_src)
 { BNR_LAUNCH(k_tail, dim3(1, 1, x.nb), dim3(1024), (size_t)x.shape->R * x.shape->V * sizeof(double), x.stream, x, s, mask, xg_src); }

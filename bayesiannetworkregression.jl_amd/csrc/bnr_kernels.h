@@ -373,16 +373,21 @@ __global__ __launch_bounds__(64) void k_node(const SRC chain_src, int s, int mod
 //   PW[b][i] = sum_{e in chunk} X[i,e] W_e ;  PA[b][i] = sum X[i,e] sz_e                 (gibbs.jl:432-433)
 // which: bit0 -> W/PW, bit1 -> sz/PA, bit2 -> PG = partial X*gamma(row `P.prev` if bit3 else row P.row)
 template <class SRC>
-__global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int which)
+__global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int which, int nchains)
 {
-    const bnr_dev &cd = chain_src.get();
+    // 1-D grid = round_up(blocks, 8) x chains, decoded like k_gram / k_backproj (chains that read the same columns of X
+    // are neighbours on one XCD)
+    const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
+    const int bid = (gr / nchains) * 8 + gx;
+    const bnr_dev &cd = chain_src.at(gr % nchains);
+    if (bid >= cd.nblk_x) return;
     extern __shared__ double sh[];
     double *sW = sh, *sZ = sh + cd.chunk_x, *sG = sh + 2 * cd.chunk_x;
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     const double *row = cd.trace + (size_t)P.row * cd.rowlen;
     const double *prev = cd.trace + (size_t)P.prev * cd.rowlen;
     const int R = cd.R;
-    const int e0 = blockIdx.x * cd.chunk_x;
+    const int e0 = bid * cd.chunk_x;
     const int ne = min(cd.chunk_x, cd.q - e0);
     const double *grow = (which & 8) ? prev : row;
     for (int t = threadIdx.x; t < cd.chunk_x; t += blockDim.x) {
@@ -409,9 +414,9 @@ __global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int w
                 aw = fma(x, sW[t], aw); aa = fma(x, sZ[t], aa); ag = fma(x, sG[t], ag);
             }
         }
-        if (which & 1) cd.PW[(size_t)blockIdx.x * ld + i] = aw;
-        if (which & 2) cd.PA[(size_t)blockIdx.x * ld + i] = aa;
-        if (which & 4) cd.PG[(size_t)blockIdx.x * ld + i] = ag;
+        if (which & 1) cd.PW[(size_t)bid * ld + i] = aw;
+        if (which & 2) cd.PA[(size_t)bid * ld + i] = aa;
+        if (which & 4) cd.PG[(size_t)bid * ld + i] = ag;
     }
 }
 
@@ -940,20 +945,25 @@ __global__ __launch_bounds__(1024) void k_solve_a4(const SRC chain_src)
 //   Psum[b][0] = sum_e S_e ; Psum[b][1+3r+c] = sum_e logpdf(Normal(W_c,e, sqrt(tau2 S_e)), gamma_e)  (gibbs.jl:603-605)
 // Back-projection x_e' a4: one wavefront per column, two columns in flight, a4 in LDS, DPP wave reduction.
 template <class SRC>
-__global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, int flags)
+__global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, int flags, int nchains)
 {
-    const bnr_dev &cd = chain_src.get();
+    // 1-D grid = round_up(blocks, 8) x chains, decoded like k_gram: the workgroups of the group's chains that read the same
+    // 32 columns of X are neighbours on the same XCD and share them through its L2
+    const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
+    const int bid = (gr / nchains) * 8 + gx;               // this chain's block: 32 consecutive edges
+    const bnr_dev &cd = chain_src.at(gr % nchains);
+    if (bid >= cd.nblk_bp) return;
     extern __shared__ double sh[];          // n_pad (a4) + 64 (dots)
     double *sa = sh, *sdot = sh + cd.n_pad;
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     double *row = cd.trace + (size_t)P.row * cd.rowlen;
     const double *prev = cd.trace + (size_t)P.prev * cd.rowlen;
     const int R = cd.R, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int e0 = blockIdx.x * cd.chunk_bp, ne = min(cd.chunk_bp, cd.q - e0);
+    const int e0 = bid * cd.chunk_bp, ne = min(cd.chunk_bp, cd.q - e0);
     const size_t ld = cd.n_pad;
     const double tau2 = row[ROW_TAU2], tau = sqrt(tau2);
 #ifdef BNR_STAMPS
-#define BNR_BSTAMP(slot) do { if (tid == 0 && blockIdx.x == 7) cd.dbg[320 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define BNR_BSTAMP(slot) do { if (tid == 0 && bid == 7) cd.dbg[320 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define BNR_BSTAMP(slot) do { } while (0)
 #endif
@@ -996,7 +1006,7 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
     }
     BNR_BSTAMP(2);
     if (!(flags & 4)) { if (cap) atomicAdd((unsigned long long *)&cd.counters[2], 1ull); return; }
-    double *ps = cd.Psum + (size_t)blockIdx.x * (1 + 3 * R);
+    double *ps = cd.Psum + (size_t)bid * (1 + 3 * R);
     // per-edge terms go through LDS ([term][lane], lane-contiguous) and lane j then sums term j over the 32 edges in a
     // fixed order: one pass instead of 3R+1 wave reductions
     double *st = sh;                                  // reuse the a4 staging area: (3R + 1) x 33 doubles <= n_pad + 64
