@@ -150,25 +150,35 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     d.n_pad = round_up(n, BNR_GT);
     d.ntile = d.n_pad / BNR_GT;
     const int ntl = d.ntile * (d.ntile + 1) / 2;
-    // split K so that the Gram launch fills the chip in whole rounds of resident workgroups (gram_kg = 4: one 1024-thread
-    // workgroup per CU; 2: two 512-thread workgroups): a grid of 288 x 1024 threads on 256 CUs runs two rounds and takes
-    // twice as long as one of 252 (measured: 58 vs 31 us)
+    // split K so that a ONE-chain Gram launch fills the chip in whole rounds of one workgroup per CU: a grid of 288 workgroups
+    // on 256 CUs runs two rounds and takes twice as long as one of 252 (measured: 58 vs 31 us).  Two 512-thread workgroups fit a
+    // CU, but splitting K further to use both slots of a single chain's launch only doubles the split-K partials (measured:
+    // ksplit 14 vs 7 at n=500, V=100: one chain 211 vs 208 us per sweep, a group of 8 chains 468 vs 446 us); a lockstep
+    // group fills the second slot with the next chain's workgroups.
     {
         hipDeviceProp_t prop;
         int ncu = 256;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
         const char *ev = getenv("BNR_GRAM_KG");
         d.gram_kg = (ev && atoi(ev) == 4) ? 4 : 2;
-        const int slots = ncu * (4 / d.gram_kg);
-        double best = -1.0;
-        d.ksplit = 1;
-        for (int ks = 1; ks <= 32; ++ks) {
-            if (ks > 1 && (d.q + ks - 1) / ks < 32 * d.gram_kg) break;      // keep every K-group at least 32 columns long
-            long tasks = (long)ntl * ks;
-            double eff = (double)tasks / (double)(((tasks + slots - 1) / slots) * slots);
-            double score = eff - 0.005 * ks;                                  // fewer split-K partials when efficiency ties
-            if (score > best) { best = score; d.ksplit = ks; }
-        }
+        auto best_split = [&](int slots) {
+            double best = -1.0;
+            int bk = 1;
+            for (int ks = 1; ks <= 32; ++ks) {
+                if (ks > 1 && (d.q + ks - 1) / ks < 32 * d.gram_kg) break;  // keep every K-group at least 32 columns long
+                long tasks = (long)ntl * ks;
+                double eff = (double)tasks / (double)(((tasks + slots - 1) / slots) * slots);
+                double score = eff - 0.005 * ks;                              // fewer split-K partials when efficiency ties
+                if (score > best) { best = score; bk = ks; }
+            }
+            return bk;
+        };
+        // long K (>= 1024 columns per slice even when both slots of every CU are used): the partials are cheap next to the
+        // loop, fill both slots (n=500, V=300: 240 vs 262 us per Gram); otherwise one workgroup per CU
+        d.ksplit = best_split(2 * ncu * (d.gram_kg == 2 ? 1 : 0) + ncu * (d.gram_kg == 2 ? 0 : 1));
+        if (d.q / d.ksplit < 1024) d.ksplit = best_split(ncu);
+        const char *ek = getenv("BNR_GRAM_KSPLIT");                           // experiments only
+        if (ek && atoi(ek) > 0) d.ksplit = atoi(ek);
     }
     int kchunk = round_up((d.q + d.ksplit - 1) / d.ksplit, 8 * d.gram_kg);
     d.q_pad = kchunk * d.ksplit;
