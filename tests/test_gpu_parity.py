@@ -410,6 +410,40 @@ def test_device_summary_equals_host_summary(gpu, test1):
     assert np.allclose(sa.edge_coef["estimate"], sb.edge_coef["estimate"], rtol=0, atol=1.0001e-3)
 
 
+def test_posterior_recovers_synthetic_truth(gpu):
+    """End to end on data drawn from the model itself (SURVEY 8d generator: n=200, V=20, R=5): 8 chains x 10 000 iterations
+    as one lockstep group converge (split-Rhat < 1.1 for every gamma and xi), the posterior mean of gamma reproduces the
+    true edge coefficients, the 95 % intervals cover them, and P(xi = 1) separates the influential nodes from the rest."""
+    n, V, R, nburn, nsamp, C = 200, 20, 5, 5000, 5000, 8
+    X, y, truth = bnr_amd.make_synthetic(n, V, R, seed=3)
+    tot = nburn + nsamp
+    chains = [bnr_amd.Chain(X, y, R, tot, 99, 1)]
+    chains += [bnr_amd.Chain.like(chains[0], 99, c, tot) for c in range(2, C + 1)]
+    for ch in chains:
+        ch.init_prior()
+    g = bnr_amd.Group(chains)
+    g.run(2, nburn, tot)
+    q = V * (V + 1) // 2
+    rh = bnr_amd.rhat_from_stats(np.stack([ch.rhat_stats(nburn + 1, nsamp) for ch in chains]), nsamp)
+    assert np.nanmax(rh[:q]) < 1.1 and np.nanmax(rh[q:]) < 1.1
+    lw, hi = bnr_amd.api._summary_ranks(nsamp, 95)
+    summ = [ch.summary(nburn + 1, nsamp, lw, hi) for ch in chains]
+    mean = np.mean([s[0] for s in summ], axis=0)
+    lo, up = np.mean([s[1] for s in summ], axis=0), np.mean([s[2] for s in summ], axis=0)
+    pxi = np.mean([s[3] for s in summ], axis=0)
+    B = truth["B"]
+    assert np.corrcoef(mean, B)[0, 1] > 0.99
+    assert np.sqrt(np.mean((mean - B) ** 2)) < 0.15 * np.sqrt(np.mean(B ** 2))
+    assert np.mean((B >= lo) & (B <= up)) >= 0.93
+    assert np.all(pxi[truth["xi"] == 1] > 0.9) and np.all(pxi[truth["xi"] == 0] < 0.1)
+    for ch in chains:
+        c = ch.counters()
+        assert c["chol_fail"] == 0 and c["nan_w"] == 0 and c["sampler_cap"] == 0
+    g.close()
+    for ch in chains:
+        ch.close()
+
+
 def test_bad_arguments_are_reported(gpu):
     X, y, _ = bnr_amd.make_synthetic(8, 4, 2, seed=1)
     with pytest.raises(bnr_amd.BnrError) as e:
@@ -465,7 +499,18 @@ def test_headline_size_properties(gpu):
     o.init_prior()
     o.run(2, 4, 4)
     assert_tables_close(A, o.t, rows_got=slice(0, 4), what="headline first rows")
-    for ch in (a, b, c):
+    # the same chain as member of a lockstep group of three (blockIdx.z path of every kernel at the full size)
+    members = [bnr_amd.Chain.like(a, 20240501, cid, tot) for cid in (2, 1, 3)]
+    for m in members:
+        m.init_prior()
+    grp = bnr_amd.Group(members)
+    grp.run(2, tot, tot)
+    Gm = members[1].fetch()
+    for k in bo.COLUMNS:
+        assert np.array_equal(Gm[k], A[k]), ("group member vs chain alone", k)
+    assert not np.array_equal(members[0].fetch()["gamma"], A["gamma"])
+    grp.close()
+    for ch in (a, b, c, *members):
         ch.close()
 
 
