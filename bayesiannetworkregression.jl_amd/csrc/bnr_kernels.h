@@ -519,10 +519,10 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
         *(bnr_d2 *)(nx_ + PANEL + woff) = rj0;                                                            \
         *(bnr_d2 *)(nx_ + PANEL + 8 * BNR_GT + woff) = rj1;                                               \
     } while (0)
-#define BNR_GRAM_COMPUTE(BUF, NK2)                                                                        \
+#define BNR_GRAM_COMPUTE(BUF, K2A, K2B)                                                                   \
     do {                                                                                                  \
         const double *bufI = stg + (size_t)(BUF) * (2 * PANEL), *bufJ = bufI + PANEL;                     \
-        _Pragma("unroll") for (int k2 = 0; k2 < (NK2); ++k2) {                                            \
+        _Pragma("unroll") for (int k2 = (K2A); k2 < (K2B); ++k2) {                                        \
             const int kk = (4 * k2 + lk) * BNR_GT;                                                        \
             double a0 = bufJ[kk + ra0], a1 = bufJ[kk + ra1];                                              \
             double b0 = bufI[kk + rb0], b1 = bufI[kk + rb1];                                              \
@@ -540,12 +540,15 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
     __syncthreads();
     BNR_GSTAMP(1);
     for (int b = 0; b < nfull; ++b) {
-        BNR_GRAM_STORE((b + 1) & 1);               // batch b+1, loaded a whole batch ago
+        // first half of the batch, then the staging work of the next one, then the second half: the wait for the loads
+        // issued one batch ago and the LDS writes sit behind 8 MFMAs already in flight (measured: +4 % over staging first)
+        BNR_GRAM_COMPUTE(b & 1, 0, 2);
+        BNR_GRAM_STORE((b + 1) & 1);               // batch b+1; its buffer was released by the last barrier
         BNR_GRAM_LOAD(b + 2);
-        BNR_GRAM_COMPUTE(b & 1, 4);
+        BNR_GRAM_COMPUTE(b & 1, 2, 4);
         __syncthreads();
     }
-    if (half) { BNR_GRAM_COMPUTE(nfull & 1, 2); __syncthreads(); }
+    if (half) { BNR_GRAM_COMPUTE(nfull & 1, 0, 2); __syncthreads(); }
     (void)nbatch;
     BNR_GSTAMP(2);
     // tile element (i,j) lives at [j*64 + i]; this lane: j = wj*32 + jt*16 + (lane>>4) + 4 r, i = wi*32 + it*16 + (lane&15)
