@@ -12,10 +12,14 @@
 //   k_node      update_tau2! (scalar draw from carried sums) + update_u_xi! (one wave per node, log-space weights)
 //   k_xpass     W = lowtri(u' L u), sz = sqrt(S) z1, partial GEMVs X W and X sz          (reads X once)
 //   k_gram      X diag(S) X' by v_mfma_f64_16x16x4_f64, split-K partial tiles             (reads X once)
-//   k_gram_reduce, k_chol_panel   G + I = L L'
-//   k_solve     a4 = (G+I)^-1 (a1 - a3); X gamma_new from n-vectors (no third pass over X)
+//   k_gram_reduce, k_chol_step x n_pad/32   E = [G + I ; I] -> [L ; L^-T]  (right-looking blocked Cholesky, one launch per panel)
+//   k_rhs, k_solve_w, k_solve_a4   a4 = (G+I)^-1 (a1 - a3) = Y (Y' b); X gamma_new from n-vectors (no third pass over X)
 //   k_backproj  gamma (back-projection X' a4), update_D! (GIG draws), partial sums for theta and Lambda (reads X once)
 //   k_tail      update_theta!, update_Delta!, update_M!, update_mu!, update_Lambda!, update_pi!, carried sums
+// Every sweep kernel exists for ONE chain (descriptor by value: bnr_one) and for a lockstep group of chains (device array
+// of descriptors indexed by the grid's chain coordinate: bnr_many); the arithmetic of a chain is the same in both.
+// Outside the sweep: k_init_prior (initialize_variables!), k_fetch_cols / k_load_cols (Table layout), k_rhat_stats
+// (split-Rhat message), k_summary (Summary statistics).
 #pragma once
 #include "bnr_rng.h"
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BNR_ABI_VERSION 1
+#define BNR_ABI_VERSION 2   /* 2: + bnr_chain_create_like, bnr_group_*, bnr_chain_summary (additive) */
 
 enum {
     BNR_OK = 0,

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "libbnr_hip.so does not export %s" % name
     assert declared == set(bnr_amd.EXPORTS), declared ^ set(bnr_amd.EXPORTS)
-    assert L.bnr_abi_version() == 1
+    assert L.bnr_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_gpu():
