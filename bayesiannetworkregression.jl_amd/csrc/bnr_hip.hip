@@ -25,6 +25,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // together (blockIdx.z = member).  Kernels read their chain's bnr_dev from the device array `cds`.
 struct bnr_exec {
     int device = 0;
+    int ncu = 256;                                      // compute units of the device
     int nb = 1;                                         // chains issued together
     bnr_dev *cds = nullptr;                             // device array of nb structs
     const bnr_dev *shape = nullptr;                     // host struct of member 0 (sizes are equal for all members)
@@ -313,6 +314,10 @@ static void drop_graph(bnr_exec &x)
 static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape)
 {
     x.device = device; x.nb = nb; x.shape = shape;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) x.ncu = prop.multiProcessorCount;
+    }
     HIPCHK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&x.stream2, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void **)&x.cds, sizeof(bnr_dev) * nb));
@@ -426,11 +431,15 @@ static void launch_rhs(bnr_exec &x, int s) { BNR_LAUNCH(k_rhs, dim3(x.shape->n_p
 static void launch_chol(bnr_exec &x, int s, hipStream_t st)
 {
     const int nbk = x.shape->n_pad / BNR_NB;
-    // update workgroups take `tpw` blocks each: one for a single chain (they are off the critical path and there are few),
-    // four in a group so that panels + updates of all members fit the chip in one round (2 workgroups per CU)
-    const int tpw = x.nb > 1 ? 4 : 1;
-    for (int p = 0; p < nbk; ++p)
-        BNR_LAUNCH(k_chol_step, dim3(x.nb, bnr_chol_npanel(nbk, p) + (bnr_chol_ntile(nbk, p) + tpw - 1) / tpw), dim3(256), 0, st, x, p, s, tpw);
+    // update workgroups take `tpw` blocks each, chosen per panel so that panels + updates of all members fit the chip in
+    // one round (two 256-thread workgroups per CU): one block each while they are few, up to eight for large n or groups
+    const int ncu = x.ncu;
+    for (int p = 0; p < nbk; ++p) {
+        const int npan = bnr_chol_npanel(nbk, p), ntile = bnr_chol_ntile(nbk, p);
+        const int room = std::max(64, 2 * ncu - x.nb * npan);
+        const int tpw = std::min(8, std::max(1, (x.nb * ntile + room - 1) / room));
+        BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + (ntile + tpw - 1) / tpw), dim3(256), 0, st, x, p, s, tpw);
+    }
 }
 static void launch_solve(bnr_exec &x)
 {
