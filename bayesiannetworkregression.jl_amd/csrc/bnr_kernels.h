@@ -991,28 +991,55 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
     }
     __syncthreads();
     BNR_BSTAMP(1);
-    if (wave != 0) return;
+    // update_D! (gibbs.jl:454-458): the rejection attempts of one GIG draw are independent given their counter, so several
+    // attempts of every edge are evaluated side by side (half-wave = 32 edges x one attempt) and the first accepted one is
+    // taken -- the same draw as the sequential loop of bnr_gig, in ~1 round instead of 3-5 dependent ones.  One chain: all
+    // four waves (attempts 8 r + 0..7), the block is latency-bound; lockstep group: wave 0 only (attempts 2 r + 0..1), the
+    // launch is throughput-bound and speculative attempts that are thrown away cost what they save.
+    __shared__ double s_val[8][32];
+    __shared__ int s_acc[8][32];
     int cap = 0;
-    const int e = e0 + lane;
-    const bool act = lane < ne;
+    const int nslot = nchains == 1 ? 8 : 2;
+    if (2 * wave >= nslot) return;
+    const int el32 = lane & 31, slot = wave * 2 + (lane >> 5);
+    const int e = e0 + el32;
+    const bool act = el32 < ne;
     double gam = 0.0, Snew = 1.0, W = 0.0;
     int l = 0, k = 0;
     if (act) {
         W = cd.Wbuf[e]; l = cd.el[e]; k = cd.ek[e];
         if (flags & 1) {
             double Sp = prev[cd.o_S + e];
-            gam = tau * (cd.sz[e] + Sp * sdot[lane]) + W;
-            row[cd.o_gamma + e] = gam;
+            gam = tau * (cd.sz[e] + Sp * sdot[el32]) + W;
+            if (slot == 0) row[cd.o_gamma + e] = gam;
         } else gam = row[cd.o_gamma + e];
-        if (flags & 2) {
-            double g = gam - W;
-            double chi = (g * g) / tau2;
-            Snew = bnr_gig(cd.seed, 0.5, chi, prev[ROW_THETA], P.it, (uint32_t)e, &cap);
-            row[cd.o_S + e] = Snew;
-        } else Snew = row[cd.o_S + e];
     }
+    if (flags & 2) {
+        const double g = gam - W, chi = (g * g) / tau2, psi = prev[ROW_THETA];
+        bnr_gig_ctx gc;
+        gc.kind = 4;
+        if (act) bnr_gig_setup(gc, 0.5, chi, psi);
+        const bool loop = act && (gc.kind == 2 || gc.kind == 3);
+        bool done = !loop;
+        for (uint32_t base = 0; base < BNR_MAX_ATTEMPTS; base += (uint32_t)nslot) {
+            double v = 0.0;
+            const bool ok = !done && bnr_gig_try(gc, cd.seed, P.it, (uint32_t)e, base + (uint32_t)slot, v);
+            s_acc[slot][el32] = ok ? 1 : 0;
+            s_val[slot][el32] = v;
+            __syncthreads();
+            if (!done) {
+#pragma unroll
+                for (int a = 7; a >= 0; --a) if (a < nslot && s_acc[a][el32]) { Snew = s_val[a][el32]; done = true; }   // lowest accepted attempt wins
+            }
+            if (!__syncthreads_or(done ? 0 : 1)) break;
+        }
+        if (!done) { cap = 1; Snew = gc.alpha * gc.xm; }                      // attempt cap, as bnr_gig
+        if (act && !loop) Snew = bnr_gig_degenerate(gc, cd.seed, chi, psi, P.it, (uint32_t)e, &cap);
+        if (act && slot == 0) row[cd.o_S + e] = Snew;
+    } else if (act) Snew = row[cd.o_S + e];
+    if (wave != 0) return;
     BNR_BSTAMP(2);
-    if (!(flags & 4)) { if (cap) atomicAdd((unsigned long long *)&cd.counters[2], 1ull); return; }
+    if (!(flags & 4)) { if (cap && lane < 32) atomicAdd((unsigned long long *)&cd.counters[2], 1ull); return; }
     double *ps = cd.Psum + (size_t)bid * (1 + 3 * R);
     // per-edge terms go through LDS ([term][lane], lane-contiguous) and lane j then sums term j over the 32 edges in a
     // fixed order: one pass instead of 3R+1 wave reductions
@@ -1040,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
         ps[j] = acc;
     }
     BNR_BSTAMP(3);
-    if (cap) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
+    if (cap && lane < 32) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
 }
 
 // ===================================================================================== k_tail

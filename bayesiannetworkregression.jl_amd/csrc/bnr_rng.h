@@ -107,26 +107,33 @@ BNR_HD double bnr_gig_mode(double lambda, double omega)   // gig.jl:170-176
     return omega / (sqrt((1.0 - lambda) * (1.0 - lambda) + omega * omega) + (1.0 - lambda));
 }
 
-// sample_gig(rng, lambda, chi, psi), gig.jl:8-42, with the three rejection branches (44-168).
+// sample_gig(rng, lambda, chi, psi), gig.jl:8-42, with the three rejection branches (44-168), split into the setup of a
+// draw and ONE rejection attempt, so that a kernel can evaluate several attempts of the same draw side by side (attempt k
+// uses the variates of counter {it, SITE_D_GIG, elem, k}: the first accepted attempt is the draw, whoever evaluates it).
 // Quirks kept: no exception for invalid parameters (9-13); Gamma SCALE psi/2 in the chi~0 branch (17).
-BNR_HD double bnr_gig(uint64_t seed, double lambda, double chi, double psi, uint32_t it, uint32_t elem, int *cap)
+struct bnr_gig_ctx {
+    int kind;                    // 0: chi ~ 0 (Gamma), 1: psi ~ 0 (inverse Gamma), 2: ratio of uniforms, 3: concave, 4: none (NaN)
+    double lambda_old, lambda, alpha, omega, xm;
+    double t, s, nc, ulo, uhi, xoff;                       // ratio of uniforms (shift and no-shift share one loop)
+    double x0, k0, A0, A1, A2, k1, k2, Atot, x0l;          // concave
+    int half;
+};
+BNR_HD void bnr_gig_setup(bnr_gig_ctx &c, double lambda, double chi, double psi)
 {
     const double eps10 = 2.220446049250313e-16 * 10.0;
-    if (chi < eps10) {
-        if (lambda > 0.0) return bnr_gamma(seed, lambda, it, SITE_D_GAMMA, elem, cap) * (psi / 2.0);
-        return 1.0 / (bnr_gamma(seed, -lambda, it, SITE_D_GAMMA, elem, cap) * (psi / 2.0));
-    } else if (psi < eps10) {
-        if (lambda > 0.0) return 1.0 / (bnr_gamma(seed, lambda, it, SITE_D_GAMMA, elem, cap) * (chi / 2.0));
-        return bnr_gamma(seed, -lambda, it, SITE_D_GAMMA, elem, cap) * (chi / 2.0);
-    }
-    const double lambda_old = lambda;
+    c.lambda_old = lambda; c.lambda = lambda; c.alpha = 0.0; c.omega = 0.0; c.xm = 0.0;
+    if (chi < eps10) { c.kind = 0; return; }
+    if (psi < eps10) { c.kind = 1; return; }
     if (lambda < 0.0) lambda = -lambda;
+    c.lambda = lambda;
     const double alpha = sqrt(chi / psi), omega = sqrt(psi * chi);
+    c.alpha = alpha; c.omega = omega;
     const bool shift = (lambda > 2.0 || omega > 3.0);
     if (shift || lambda >= 1.0 - 2.25 * (omega * omega) || omega > 0.2) {
         // gig_ROU_shift (gig.jl:44-78) and gig_ROU_noshift (gig.jl:80-100) share one rejection loop:
         //   U = ulo + ru (uhi - ulo), X = U / V + xoff;  no-shift is (ulo, uhi, xoff) = (0, um, 0), bit-identical to um*ru, U/V.
         // One loop instead of two keeps a wavefront whose lanes are split over the branches from running them back to back.
+        c.kind = 2;
         double t = 0.5 * (lambda - 1.0), s = 0.25 * omega;
         double xm = bnr_gig_mode(lambda, omega);
         double nc = t * log(xm) - s * (xm + 1.0 / xm);
@@ -134,9 +141,9 @@ BNR_HD double bnr_gig(uint64_t seed, double lambda, double chi, double psi, uint
         if (shift) {
             double a = -(2.0 * (lambda + 1.0) / omega + xm);
             double b = (2.0 * (lambda - 1.0) * xm / omega - 1.0);
-            double c = xm;
+            double cc = xm;
             double p = b - a * a / 3.0;
-            double q = 2.0 * a * a * a / 27.0 - a * b / 3.0 + c;
+            double q = 2.0 * a * a * a / 27.0 - a * b / 3.0 + cc;
             double fi = acos(-q / (2.0 * sqrt(-p * p * p / 27.0)));
             double fak = 2.0 * sqrt(-p / 3.0);
             double y1 = fak * cos(fi / 3.0) - a / 3.0;
@@ -150,19 +157,12 @@ BNR_HD double bnr_gig(uint64_t seed, double lambda, double chi, double psi, uint
             ulo = 0.0;
             xoff = 0.0;
         }
-        for (uint32_t k = 0; k < BNR_MAX_ATTEMPTS; ++k) {
-            double ru, rv;
-            bnr_draw2(seed, it, SITE_D_GIG, elem, k, ru, rv);
-            double U = ulo + ru * (uhi - ulo);
-            double X = U / rv + xoff;
-            if (X > 0.0 && log(rv) <= t * log(X) - s * (X + 1.0 / X) - nc)
-                return lambda_old < 0.0 ? alpha / X : alpha * X;
-        }
-        if (cap) *cap = 1;
-        return alpha * xm;
+        c.t = t; c.s = s; c.xm = xm; c.nc = nc; c.ulo = ulo; c.uhi = uhi; c.xoff = xoff;
+        return;
     }
     if (lambda >= 0.0 && omega > 0.0) {
         // gig_concave, gig.jl:102-168.  For lambda = 1/2 (the only value update_D! uses) the powers are square roots.
+        c.kind = 3;
         const bool half = (lambda == 0.5);
         double xm = bnr_gig_mode(lambda, omega);
         double x0 = omega / (1.0 - lambda);
@@ -182,33 +182,74 @@ BNR_HD double bnr_gig(uint64_t seed, double lambda, double chi, double psi, uint
             k2 = half ? 1.0 / twl : pow(tw, lambda - 1.0);
             A2 = k2 * 2.0 * exp(-1.0) / omega;
         }
-        double Atot = A0 + A1 + A2;
-        for (uint32_t k = 0; k < BNR_MAX_ATTEMPTS; ++k) {
-            double ru, rv;
-            bnr_draw2(seed, it, SITE_D_GIG, elem, k, ru, rv);
-            double Vv = Atot * ru, hx, X;
-            if (Vv <= A0) { X = x0 * Vv / A0; hx = k0; }
-            else {
-                Vv -= A0;
-                if (Vv <= A1) {
-                    if (lambda == 0.0) { X = omega * exp(exp(omega) * Vv); hx = k1 / X; }
-                    else if (half) { double r = x0l + (lambda / k1 * Vv); X = r * r; hx = k1 / r; }
-                    else { X = pow(x0l + (lambda / k1 * Vv), 1.0 / lambda); hx = k1 * pow(X, lambda - 1.0); }
-                } else {
-                    Vv -= A1;
-                    double a = (x0 > 2.0 / omega) ? x0 : 2.0 / omega;
-                    X = -2.0 / omega * log(exp(-omega / 2.0 * a) - omega / (2.0 * k2) * Vv);
-                    hx = k2 * exp(-omega / 2.0 * X);
-                }
-            }
-            double U = rv * hx;
-            if (log(U) <= (lambda - 1.0) * log(X) - omega / 2.0 * (X + 1.0 / X))
-                return lambda_old < 0.0 ? alpha / X : alpha * X;
+        c.half = half ? 1 : 0; c.xm = xm; c.x0 = x0; c.k0 = k0; c.A0 = A0; c.A1 = A1; c.A2 = A2; c.k1 = k1; c.k2 = k2;
+        c.Atot = A0 + A1 + A2; c.x0l = x0l;
+        return;
+    }
+    c.kind = 4;
+}
+// attempt k of a kind 2 / 3 draw: true and the value (already scaled by alpha) when accepted
+BNR_HD bool bnr_gig_try(const bnr_gig_ctx &c, uint64_t seed, uint32_t it, uint32_t elem, uint32_t k, double &out)
+{
+    double ru, rv;
+    bnr_draw2(seed, it, SITE_D_GIG, elem, k, ru, rv);
+    if (c.kind == 2) {
+        double U = c.ulo + ru * (c.uhi - c.ulo);
+        double X = U / rv + c.xoff;
+        if (X > 0.0 && log(rv) <= c.t * log(X) - c.s * (X + 1.0 / X) - c.nc) {
+            out = c.lambda_old < 0.0 ? c.alpha / X : c.alpha * X;
+            return true;
         }
-        if (cap) *cap = 1;
-        return alpha * xm;
+        return false;
+    }
+    const double lambda = c.lambda, omega = c.omega;
+    double Vv = c.Atot * ru, hx, X;
+    if (Vv <= c.A0) { X = c.x0 * Vv / c.A0; hx = c.k0; }
+    else {
+        Vv -= c.A0;
+        if (Vv <= c.A1) {
+            if (lambda == 0.0) { X = omega * exp(exp(omega) * Vv); hx = c.k1 / X; }
+            else if (c.half) { double r = c.x0l + (lambda / c.k1 * Vv); X = r * r; hx = c.k1 / r; }
+            else { X = pow(c.x0l + (lambda / c.k1 * Vv), 1.0 / lambda); hx = c.k1 * pow(X, lambda - 1.0); }
+        } else {
+            Vv -= c.A1;
+            double a = (c.x0 > 2.0 / omega) ? c.x0 : 2.0 / omega;
+            X = -2.0 / omega * log(exp(-omega / 2.0 * a) - omega / (2.0 * c.k2) * Vv);
+            hx = c.k2 * exp(-omega / 2.0 * X);
+        }
+    }
+    double U = rv * hx;
+    if (log(U) <= (lambda - 1.0) * log(X) - omega / 2.0 * (X + 1.0 / X)) {
+        out = c.lambda_old < 0.0 ? c.alpha / X : c.alpha * X;
+        return true;
+    }
+    return false;
+}
+// the draws that need no rejection loop of their own (kinds 0, 1, 4)
+BNR_HD double bnr_gig_degenerate(const bnr_gig_ctx &c, uint64_t seed, double chi, double psi, uint32_t it, uint32_t elem, int *cap)
+{
+    const double lambda = c.lambda_old;
+    if (c.kind == 0) {
+        if (lambda > 0.0) return bnr_gamma(seed, lambda, it, SITE_D_GAMMA, elem, cap) * (psi / 2.0);
+        return 1.0 / (bnr_gamma(seed, -lambda, it, SITE_D_GAMMA, elem, cap) * (psi / 2.0));
+    }
+    if (c.kind == 1) {
+        if (lambda > 0.0) return 1.0 / (bnr_gamma(seed, lambda, it, SITE_D_GAMMA, elem, cap) * (chi / 2.0));
+        return bnr_gamma(seed, -lambda, it, SITE_D_GAMMA, elem, cap) * (chi / 2.0);
     }
     return NAN;   // the reference returns `nothing` here (gig.jl:41)
+}
+BNR_HD double bnr_gig(uint64_t seed, double lambda, double chi, double psi, uint32_t it, uint32_t elem, int *cap)
+{
+    bnr_gig_ctx c;
+    bnr_gig_setup(c, lambda, chi, psi);
+    if (c.kind != 2 && c.kind != 3) return bnr_gig_degenerate(c, seed, chi, psi, it, elem, cap);
+    for (uint32_t k = 0; k < BNR_MAX_ATTEMPTS; ++k) {
+        double out;
+        if (bnr_gig_try(c, seed, it, elem, k, out)) return out;
+    }
+    if (cap) *cap = 1;
+    return c.alpha * c.xm;
 }
 
 // StatsBase.sample(rng, vals, weights): linear scan of the cumulative weights; order [0,1,-1] (gibbs.jl:207,610)
