@@ -681,21 +681,37 @@ __device__ __forceinline__ int bnr_sweep16(double (&a)[16], int lane, double (*s
 {
     int bad = 0;
     double lprev = 0.0;
+    // The only truly sequential part of the factorization is the chain pivot -> 1/sqrt -> next pivot.  It is kept on
+    // wave-uniform scalars: with s1 = a[j+1] and s2 = a[j] at row j+1 (read by v_readlane BEFORE column j is scaled, i.e.
+    // off the chain), l_{j+1,j} = s2 rinv and the next pivot is fma(-l, l, s1) -- exactly the operations the vector
+    // update performs on that lane, so the results are bitwise those of the plain column sweep, but the chain per pivot is
+    // rsq + 2 Newton steps + 2 operations instead of also scaling the column, broadcasting it and updating the next one.
+    double piv = bnr_readlane(a[0], COFF);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         double tk[16];
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (j + 1 < 16) { s1 = bnr_readlane(a[j + 1], COFF + j + 1); s2 = bnr_readlane(a[j], COFF + j + 1); }
+        if (j + 2 < 16) s3 = bnr_readlane(a[j], COFF + j + 2);
+        if (!(piv > 0.0)) bad = 1;                       // not positive definite: NaNs from here on, reported by the caller
+        // the reciprocal square root is started BEFORE the wait for the previous column's LDS write: the wave issues in
+        // order, so the v_rsq_f64 (quarter rate, long latency) runs while the LDS round trip completes
+        double y = __builtin_amdgcn_rsq(piv);
         if (j >= 1) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(y) : "memory");
 #pragma unroll
             for (int k = j + 2; k < 16; ++k) tk[k] = sCol[(j - 1) & 1][COFF + k];
         }
-        double piv = bnr_readlane(a[j], COFF + j);
-        if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
-        double rinv = bnr_rsqrt(piv);
+        double e = fma(-piv * y, y, 1.0);
+        y = fma(y * 0.5, e, y);
+        e = fma(-piv * y, y, 1.0);
+        const double rinv = fma(y * 0.5, e, y);
+        const double t1 = s2 * rinv;                     // l_{j+1,j}
+        piv = fma(-t1, t1, s1);                          // next pivot
         double lj = a[j] * rinv;
         a[j] = lj;
-        if (j + 1 < 16) a[j + 1] = fma(-lj, bnr_readlane(lj, COFF + j + 1), a[j + 1]);
-        if (j + 2 < 16) a[j + 2] = fma(-lj, bnr_readlane(lj, COFF + j + 2), a[j + 2]);
+        if (j + 1 < 16) a[j + 1] = fma(-lj, t1, a[j + 1]);
+        if (j + 2 < 16) a[j + 2] = fma(-lj, s3 * rinv, a[j + 2]);
         if (lane < 32) sCol[j & 1][lane] = lj;
         if (j >= 1) {
 #pragma unroll
