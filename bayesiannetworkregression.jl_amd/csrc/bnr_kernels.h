@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const SRC chain_src, int s)
 // Every block row of E (matrix rows, identity rows, the b block) runs the same code:
 //   role A (nbk + 2 panel workgroups): apply panel p-1's update to the blocks (p,p) and (rho,p) by f64 MFMA (operands
 //       loaded from L2 straight in fragment layout), then ONE wavefront sweeps the 64 x 32 register-resident panel
-//       [E_pp ; E_rho,p] column by column: pivot broadcast by v_readlane, rsqrt = v_rsq_f64 + 2 Newton steps, rank-1 updates of
+//       [E_pp ; E_rho,p] column by column: pivot chain on scalars, rsqrt = v_rsq_f64 + one third-order step, rank-1 updates of
 //       the next two columns with v_readlane broadcasts, of the remaining columns one step later with LDS broadcast reads
 //       (software pipelined so that the LDS latency hides behind the next pivot's rsqrt chain).
 //       Lanes 0-31 redo the diagonal block in every workgroup: no cross-workgroup hand-off inside a launch.
@@ -635,16 +635,6 @@ __device__ __forceinline__ double bnr_readlane(double v, int srclane)
     hi = __builtin_amdgcn_readlane(hi, srclane);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double bnr_rsqrt(double x)
-{
-    double y = __builtin_amdgcn_rsq(x);
-    double e = fma(-x * y, y, 1.0);
-    y = fma(y * 0.5, e, y);
-    e = fma(-x * y, y, 1.0);
-    y = fma(y * 0.5, e, y);
-    return y;
-}
-
 #define BNR_LP (BNR_NB + 1)
 __host__ __device__ inline int bnr_chol_npanel(int nbk, int p) { (void)p; return nbk + 1; }
 __host__ __device__ inline int bnr_chol_ntile(int nbk, int p)
@@ -702,10 +692,10 @@ __device__ __forceinline__ int bnr_sweep16(double (&a)[16], int lane, double (*s
 #pragma unroll
             for (int k = j + 2; k < 16; ++k) tk[k] = sCol[(j - 1) & 1][COFF + k];
         }
-        double e = fma(-piv * y, y, 1.0);
-        y = fma(y * 0.5, e, y);
-        e = fma(-piv * y, y, 1.0);
-        const double rinv = fma(y * 0.5, e, y);
+        // v_rsq_f64 is good to 2^-24 (tools/rsq_precision.hip); ONE third-order step y (1 + e/2 + 3 e^2/8), e = 1 - x y^2,
+        // gives 1.2 ulp -- what two Newton steps give -- in 5 instead of 8 operations and depth 4 instead of 6
+        const double e = fma(-(piv * y), y, 1.0);
+        const double rinv = fma(y * e, fma(0.375, e, 0.5), y);
         const double t1 = s2 * rinv;                     // l_{j+1,j}
         piv = fma(-t1, t1, s1);                          // next pivot
         double lj = a[j] * rinv;
