@@ -9,7 +9,7 @@ Sources (all DATA files of the reference's own test-suite / examples, no source 
        (file written by test/gen_tst_results.jl:238, read by test/init-tests.jl:39,
         toy-generate-samples-test.jl:16, test1-generate-samples-test.jl:8)
   test/data/test1.csv              -> test1_xy.npz      (test1-generate-samples-test.jl:3-5)
-  examples/matrix_networks.csv + responses.csv -> examples_xy.npz (BASELINE.json configs[0])
+  examples/matrix_networks.csv + responses.csv + true_b.csv + true_xi.csv -> examples_xy.npz (BASELINE.json configs[0])
 
 The JLD2 container is plain HDF5 (superblock v2 at byte 512, v2 object headers,
 contiguous / compact layouts, no compression), so a minimal reader suffices; neither
@@ -175,8 +175,13 @@ def main():
     y = np.loadtxt(os.path.join(REF, "examples/responses.csv"), delimiter=",", skiprows=1)
     assert X.shape == (100, 466) and np.array_equal(X[:, 465], y)   # last csv column is y itself
     X = X[:, :465]                                                  # V=30 incl. diagonal
-    print("examples", X.shape, y.shape)
-    np.savez_compressed(os.path.join(OUT, "examples_xy.npz"), X=X, y=y)
+    # the truth the example data was simulated from (examples/true_b.csv: the 435 off-diagonal edge coefficients,
+    # examples/true_xi.csv: which of the 30 nodes are influential)
+    true_b = np.loadtxt(os.path.join(REF, "examples/true_b.csv"), skiprows=1)
+    true_xi = np.array([ln.strip() == "true" for ln in open(os.path.join(REF, "examples/true_xi.csv")).read().split()[1:]], dtype=float)
+    assert true_b.shape == (435,) and true_xi.shape == (30,)
+    print("examples", X.shape, y.shape, true_b.shape, true_xi.sum())
+    np.savez_compressed(os.path.join(OUT, "examples_xy.npz"), X=X, y=y, true_b=true_b, true_xi=true_xi)
     for fn in sorted(os.listdir(OUT)):
         if fn.endswith(".npz"):
             print(fn, os.path.getsize(os.path.join(OUT, fn)))

@@ -444,6 +444,28 @@ def test_posterior_recovers_synthetic_truth(gpu):
         ch.close()
 
 
+def test_reference_example_data_through_the_drop_in_api(gpu):
+    """BASELINE.json configs[0]: the reference's example (examples/matrix_networks.csv + responses.csv: n=100, V=30, R=5)
+    through Fit! with the Summary statistics computed on the device, against the truth the example was simulated from
+    (examples/true_b.csv, true_xi.csv): the 20 influential nodes are found with probability ~1, no other node gets more than
+    0.5, and the posterior means of the 435 off-diagonal edge coefficients follow true_b."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "examples_xy.npz"))
+    X, y, tb, txi = d["X"], d["y"], d["true_b"], d["true_xi"]
+    res = bnr_amd.Fit(X, y, 5, nburn=4000, nsamples=4000, num_chains=4, seed=1234, x_transform=False, suppress_timer=True,
+                      filename=None, psrf_cutoff=1.3, return_state=False, summary_interval=95)
+    assert res.state is None and res.sampled == 4000
+    s = bnr_amd.Summary(res)
+    off = s.edge_coef["node1"] != s.edge_coef["node2"]
+    assert off.sum() == 435
+    est = res.summary_device["estimate"][off]
+    assert np.corrcoef(est, tb)[0, 1] > 0.75
+    p = res.summary_device["probability"]
+    assert np.all(p[txi == 1] > 0.9) and np.all(p[txi == 0] < 0.5)
+    lo, hi = res.summary_device["lower_bound"][off], res.summary_device["upper_bound"][off]
+    assert np.mean((tb >= lo) & (tb <= hi)) > 0.8
+    assert len(str(s).splitlines()) == 3 + 465 + 1 + 30
+
+
 def test_bad_arguments_are_reported(gpu):
     X, y, _ = bnr_amd.make_synthetic(8, 4, 2, seed=1)
     with pytest.raises(bnr_amd.BnrError) as e:
