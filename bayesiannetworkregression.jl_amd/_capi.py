@@ -56,6 +56,8 @@ _SIGS = {
     "bnr_chain_rhat_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
     "bnr_chain_summary": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]),
     "bnr_rhat_from_stats": (C.c_int, [_dp, C.c_int32, C.c_int32, C.c_int32, _dp]),
+    "bnr_chain_ess_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp]),
+    "bnr_ess_from_stats": (C.c_int, [_dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "bnr_chain_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "bnr_chain_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "bnr_chain_last_timing": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -239,6 +241,11 @@ class Chain:
         check(self.L.bnr_chain_summary(self.h, first_row, nsamp, k_lo, k_hi, _ptr(mean), _ptr(lo), _ptr(hi), _ptr(pxi)))
         return mean, lo, hi, pxi
 
+    def ess_stats(self, first_row, nsamp, max_lag):
+        out = np.empty(2 * (2 + max_lag) * (self.q + self.V))
+        check(self.L.bnr_chain_ess_stats(self.h, first_row, nsamp, max_lag, _ptr(out)))
+        return out
+
     def counters(self):
         out = (C.c_int64 * 8)()
         check(self.L.bnr_chain_counters(self.h, out))
@@ -306,6 +313,16 @@ class Group:
         us, n = C.c_double(0), C.c_int64(0)
         check(self.L.bnr_group_last_timing(self.h, which, C.byref(us), C.byref(n)))
         return us.value, n.value
+
+
+def ess_from_stats(stats, nsamp, max_lag):
+    """Bulk effective sample size from the gathered per-chain messages (nchains, 2 * (2 + max_lag) * nparams)."""
+    st = np.ascontiguousarray(stats, dtype=np.float64)
+    nch = st.shape[0]
+    npar = st.shape[1] // (2 * (2 + max_lag))
+    out = np.empty(npar)
+    check(lib().bnr_ess_from_stats(_ptr(st), nch, npar, nsamp, max_lag, _ptr(out)))
+    return out
 
 
 def rhat_from_stats(stats, nsamp):

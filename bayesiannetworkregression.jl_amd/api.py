@@ -27,7 +27,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _capi
-from ._capi import Chain, Group, new_table, rhat_from_stats
+from ._capi import Chain, Group, ess_from_stats, new_table, rhat_from_stats
 
 CITATION = ("If you use BayesianNetworkRegression.jl, please cite:\n@article{Ozminkowski2022,\n"
             "author = {Ozminkowski, S. and Sol\\'{i}s-Lemus, C.},\nyear = {2022},\n"
@@ -81,6 +81,8 @@ class Results:
     burn_in: int
     sampled: int
     summary_device: dict = None      # filled on request: Summary statistics computed on the GPU (see Summary)
+    essxi: np.ndarray = None         # filled on request (ess_max_lag=...): bulk effective sample sizes over all chains
+    essgamma: np.ndarray = None
 
 
 @dataclass
@@ -246,6 +248,15 @@ class ChainSet:
         q = (allst.shape[1] // 4) - self._V_from_width(allst.shape[1] // 4)
         return r[:q], r[q:]
 
+    def ess(self, first_row, nsamp, max_lag=None):
+        """Bulk effective sample size over ALL chains of the fit for gamma (q) then xi (V) -- an addition to the reference
+        (split chains + Geyer's sequence, as Stan / MCMCDiagnosticTools.ess); same exchange pattern as rhat()."""
+        max_lag = min(250, nsamp // 4) if max_lag is None else max_lag
+        local = {c: ch.ess_stats(first_row, nsamp, max_lag) for c, ch in self.chains.items()}
+        allst = allgather_stats(local, self.num_chains)
+        e = ess_from_stats(allst, nsamp, max_lag)
+        return e[:self.q], e[self.q:]
+
     @staticmethod
     def _V_from_width(npar):
         # npar = q + V = V(V+3)/2
@@ -292,8 +303,10 @@ def return_psrf_VOI(chainset, nburn, nsamp, fetch_state=True, summary_interval=N
     return Results(state, rx, rg, nburn, nsamp, dev)
 
 
-def _finish(chainset, res, return_state, summary_interval):
+def _finish(chainset, res, return_state, summary_interval, ess_max_lag=None):
     """The Results a fit returns: chain 1's table (states[1], gibbs.jl:788) and/or its Summary statistics from the device."""
+    if ess_max_lag is not None:                       # collective over ranks, like the PSRF
+        res.essgamma, res.essxi = chainset.ess(res.burn_in + 1, res.sampled, ess_max_lag if ess_max_lag > 0 else None)
     if 1 in chainset.chains:
         ch = chainset.chains[1]
         if return_state:
@@ -330,7 +343,7 @@ def _normalize_purge(purge_burn, nburn):
 
 def generate_samples(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1.0, nu=10, nburn=30000, nsamp=20000,
                      maxburn=50000, psrf_cutoff=1.2, x_transform=True, suppress_timer=False, num_chains=2, seed=None,
-                     purge_burn=None, device=None, _keep=None, return_state=True, summary_interval=None):
+                     purge_burn=None, device=None, _keep=None, return_state=True, summary_interval=None, ess_max_lag=None):
     """generate_samples! (gibbs.jl:897-1020): "traditional" scheme with PSRF-driven top-up rounds."""
     if nu < R:
         pass                                       # the reference constructs an ArgumentError without throwing it (901-902)
@@ -378,7 +391,7 @@ def generate_samples(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1
         print("%d samples generated. Max PSRF XI: %.3f. Max PSRF Gamma: %.3f" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()), file=sys.stderr)
     print("R = %s nu=%s nburn= %d nsamp = %d" % (R, nu, nburn, nsamp))
     print("%d samples generated. Max PSRF XI: %.3f. Max PSRF Gamma: %.3f\n" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()))
-    res = _finish(cs, res, return_state, summary_interval)
+    res = _finish(cs, res, return_state, summary_interval, ess_max_lag)
     if _keep is None:
         cs.close()
     return res
@@ -386,7 +399,7 @@ def generate_samples(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1
 
 def generate_samples_dbl(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1.0, nu=10, mingen=10000,
                          maxgen=100000, psrf_cutoff=1.01, x_transform=True, suppress_timer=False, num_chains=2,
-                         seed=None, purge_burn=None, device=None, return_state=True, summary_interval=None):
+                         seed=None, purge_burn=None, device=None, return_state=True, summary_interval=None, ess_max_lag=None):
     """generate_samples_dbl! (gibbs.jl:1051-1198): "doubling generation" scheme."""
     if nu == R:
         print("Warning: ν==R may give poor accuracy. Consider increasing ν")
@@ -436,17 +449,18 @@ def generate_samples_dbl(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDel
         print("%d samples generated. Max PSRF XI: %.3f. Max PSRF Gamma: %.3f" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()), file=sys.stderr)
     print("\nR = %s nu=%s nburn= %d nsamp = %d\n" % (R, nu, nburn, nsamp))
     print("%d samples generated. Max PSRF XI: %.4f. Max PSRF Gamma: %.4f" % (tot_generated, res.rhatxi.max(), res.rhatgamma.max()))
-    res = _finish(cs, res, return_state, summary_interval)
+    res = _finish(cs, res, return_state, summary_interval, ess_max_lag)
     cs.close()
     return res
 
 
 def Fit(X, y, R, eta=1.01, V=30, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1.0, nu=10, nburn=30000, nsamples=20000,
         mingen=0, maxgen=0, psrf_cutoff=1.01, x_transform=True, suppress_timer=False, num_chains=2, seed=None,
-        purge_burn=None, filename="parameters.log", device=None, return_state=True, summary_interval=None):
+        purge_burn=None, filename="parameters.log", device=None, return_state=True, summary_interval=None, ess_max_lag=None):
     """Fit! (gibbs.jl:725-751).  The `V` keyword is accepted and ignored, as in the reference.
     Extensions: summary_interval=95 computes Summary's statistics on the GPU (Results.summary_device);
-    return_state=False then leaves the (large) state table on the device and frees it."""
+    return_state=False then leaves the (large) state table on the device and frees it; ess_max_lag=0 (default lag
+    window) or a lag count adds bulk effective sample sizes over all chains (Results.essgamma / essxi)."""
     seed = random.randrange(1, 55556) if seed is None else seed           # sample(1:55555) :739
     if _rank_world()[0] == 0 and filename:
         with open(filename, "w") as f:
@@ -462,8 +476,8 @@ def Fit(X, y, R, eta=1.01, V=30, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1.0, nu=
         return generate_samples_dbl(X, y, R, eta=eta, zeta=zeta, iota=iota, aDelta=aDelta, bDelta=bDelta, nu=nu, mingen=mingen,
                                     maxgen=maxgen, psrf_cutoff=psrf_cutoff, x_transform=x_transform, suppress_timer=suppress_timer,
                                     num_chains=num_chains, seed=seed, purge_burn=purge_burn, device=device,
-                                    return_state=return_state, summary_interval=summary_interval)
+                                    return_state=return_state, summary_interval=summary_interval, ess_max_lag=ess_max_lag)
     return generate_samples(X, y, R, eta=eta, zeta=zeta, iota=iota, aDelta=aDelta, bDelta=bDelta, nu=nu, nburn=nburn, nsamp=nsamples,
                             maxburn=nburn + nsamples, psrf_cutoff=psrf_cutoff, x_transform=x_transform,
                             suppress_timer=suppress_timer, num_chains=num_chains, seed=seed, purge_burn=purge_burn, device=device,
-                            return_state=return_state, summary_interval=summary_interval)
+                            return_state=return_state, summary_interval=summary_interval, ess_max_lag=ess_max_lag)

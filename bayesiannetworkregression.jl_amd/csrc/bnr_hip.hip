@@ -1076,6 +1076,81 @@ int bnr_chain_summary(bnr_chain *c, int32_t first_row, int32_t nsamp, int32_t k_
     return check_launch("k_summary");
 }
 
+// Effective sample size (an addition: the reference only has split-Rhat).  Per-chain message: for both halves of the window
+// the mean, variance and the autocovariances at lags 0..max_lag-1 of gamma (q) and xi (V): 2 (2 + max_lag) (q + V) doubles.
+int bnr_chain_ess_stats(bnr_chain *c, int32_t first_row, int32_t nsamp, int32_t max_lag, double *stats)
+{
+    if (!c || !stats) return fail(BNR_ERR_BAD_ARG, "NULL argument");
+    if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");
+    const bnr_dev &d = c->d;
+    if (first_row < 1 || nsamp < 8 || first_row + nsamp - 1 > d.tot) return fail(BNR_ERR_BAD_ARG, "row window outside the table or nsamp < 8");
+    if (max_lag < 2 || max_lag > nsamp / 2) return fail(BNR_ERR_BAD_ARG, "need 2 <= max_lag <= nsamp/2");
+    HIPCHK(hipSetDevice(c->device));
+    const int np = d.q + d.V;
+    const size_t width = (size_t)2 * (2 + max_lag) * np;
+    double *buf = nullptr, *out = nullptr;
+    HIPCHK(hipMalloc((void **)&buf, sizeof(double) * (size_t)np * nsamp));
+    if (hipMalloc((void **)&out, sizeof(double) * width) != hipSuccess) { hipFree(buf); return fail(BNR_ERR_HIP, "hipMalloc failed"); }
+    dim3 block(32, 8);
+    hipLaunchKernelGGL(k_fetch_cols, dim3((d.q + 31) / 32, (nsamp + 31) / 32), block, 0, c->x.stream, (const double *)d.trace, d.rowlen, d.o_gamma, d.q, first_row - 1, nsamp, buf);
+    hipLaunchKernelGGL(k_fetch_cols, dim3((d.V + 31) / 32, (nsamp + 31) / 32), block, 0, c->x.stream, (const double *)d.trace, d.rowlen, d.o_xi, d.V, first_row - 1, nsamp, buf + (size_t)d.q * nsamp);
+    hipLaunchKernelGGL(k_acov, dim3(np, 2), dim3(256), 0, c->x.stream, (const double *)buf, nsamp, np, max_lag, out);
+    hipError_t e = hipMemcpyAsync(stats, out, sizeof(double) * width, hipMemcpyDeviceToHost, c->x.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->x.stream);
+    hipFree(buf); hipFree(out);
+    if (e != hipSuccess) return fail(BNR_ERR_HIP, std::string("ess_stats: ") + hipGetErrorString(e));
+    return check_launch("k_acov");
+}
+
+// Bulk effective sample size over all chains from the gathered messages (the estimator of Vehtari et al. 2021 as in
+// Stan / MCMCDiagnosticTools.ess: split chains, rho_t = 1 - (W - mean acov_t) / var+, Geyer's initial positive and monotone
+// sequence on the pair sums), truncated at max_lag.  NaN for a constant parameter.
+int bnr_ess_from_stats(const double *stats, int32_t nchains, int32_t nparams, int32_t nsamp, int32_t max_lag, double *ess)
+{
+    if (!stats || !ess || nchains < 1 || nparams < 1 || max_lag < 2) return fail(BNR_ERR_BAD_ARG, "bad argument");
+    const int h = nsamp / 2, m = 2 * nchains, L = max_lag;
+    const size_t hw = (size_t)(2 + L) * nparams, cw = 2 * hw;          // per half, per chain
+    std::vector<double> rho(L);
+    for (int p = 0; p < nparams; ++p) {
+        double W = 0.0, mm = 0.0;
+        for (int c = 0; c < nchains; ++c) for (int k = 0; k < 2; ++k) {
+            const double *s = stats + (size_t)c * cw + (size_t)k * hw;
+            mm += s[p]; W += s[(size_t)nparams + p];
+        }
+        mm /= m; W /= m;
+        double B = 0.0;
+        for (int c = 0; c < nchains; ++c) for (int k = 0; k < 2; ++k) {
+            const double *s = stats + (size_t)c * cw + (size_t)k * hw;
+            B += (s[p] - mm) * (s[p] - mm);
+        }
+        B /= (m - 1);
+        const double varp = W * (h - 1.0) / h + B;
+        if (!(varp > 0.0) || !(W > 0.0)) { ess[p] = NAN; continue; }
+        for (int t = 0; t < L; ++t) {
+            double ac = 0.0;
+            for (int c = 0; c < nchains; ++c) for (int k = 0; k < 2; ++k)
+                ac += stats[(size_t)c * cw + (size_t)k * hw + (size_t)(2 + t) * nparams + p];
+            ac /= m;
+            rho[t] = 1.0 - (W - ac) / varp;              // W: 1/(h-1) variances, acov_t: 1/h sums, as in Stan
+        }
+        rho[0] = 1.0;
+        // Geyer: pair sums P_t = rho_2t + rho_2t+1 while positive, made monotone; then the next even term if positive
+        double tau = -1.0, prev = INFINITY;
+        int t = 0;
+        for (; 2 * t + 1 < L; ++t) {
+            double P = rho[2 * t] + rho[2 * t + 1];
+            if (!(P > 0.0)) break;
+            if (P > prev) P = prev;
+            prev = P;
+            tau += 2.0 * P;
+        }
+        if (2 * t < L && rho[2 * t] > 0.0) tau += rho[2 * t];
+        if (tau < 1.0 / log10((double)m * h)) tau = 1.0 / log10((double)m * h);      // Stan's cap on anti-correlated chains
+        ess[p] = (double)m * h / tau;
+    }
+    return BNR_OK;
+}
+
 int bnr_rhat_from_stats(const double *stats, int32_t nchains, int32_t nparams, int32_t nsamp, double *rhat)
 {
     if (!stats || !rhat || nchains < 1 || nparams < 1) return fail(BNR_ERR_BAD_ARG, "bad argument");

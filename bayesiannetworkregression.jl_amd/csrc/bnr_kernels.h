@@ -1574,3 +1574,31 @@ __global__ __launch_bounds__(256) void k_summary(const double *buf, int nsamp, i
         __syncthreads();
     }
 }
+
+// ===================================================================================== k_acov
+// Per-chain part of an effective-sample-size estimate (an addition to the reference, which only has split-Rhat:
+// convergence.jl): for column p of the transposed window (see k_summary) and each half h of the window -- the same halves
+// split-Rhat uses -- the mean, the variance (ddof 1) and the autocovariances at lags 0..L-1 (1/n normalisation).
+// out: [half][2 + L][np] = mean, var, acov_0 .. acov_{L-1}.  One workgroup of 256 threads per (column, half): thread t owns
+// lags t, t+256, ...; every sum runs over the samples in their order (deterministic).
+__global__ __launch_bounds__(256) void k_acov(const double *buf, int nsamp, int np, int L, double *out)
+{
+    __shared__ double red[256];
+    const int p = blockIdx.x, half = blockIdx.y, tid = threadIdx.x;
+    const int h = nsamp / 2;
+    const double *x = buf + (size_t)p * nsamp + (half == 0 ? 0 : nsamp - h);
+    double acc = 0.0;
+    for (int i = tid; i < h; i += 256) acc += x[i];
+    red[tid] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (tid < w) red[tid] += red[tid + w]; __syncthreads(); }
+    const double mean = red[0] / h;
+    __syncthreads();
+    double *o = out + (size_t)half * (2 + L) * np + p;
+    for (int lag = tid; lag < L; lag += 256) {
+        double sacc = 0.0;
+        for (int i = 0; i + lag < h; ++i) sacc += (x[i] - mean) * (x[i + lag] - mean);
+        o[(size_t)(2 + lag) * np] = sacc / h;
+        if (lag == 0) { o[0] = mean; o[(size_t)np] = sacc / (h - 1); }
+    }
+}

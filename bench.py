@@ -182,6 +182,13 @@ def main():
     else:
         stats = np.stack([local[c] for c in sorted(local)])
     rh = bnr_amd.rhat_from_stats(stats, nsamp)
+    # effective sample size of the timed window over all chains (an addition to the reference's Rhat; same exchange pattern)
+    ess = None
+    if nsamp >= 64:
+        Lag = min(250, nsamp // 4)
+        local_e = {cid: ch.ess_stats(W + 2, nsamp, Lag) for cid, ch in zip(ids, chains)}
+        stats_e = bnr_amd.allgather_stats(local_e, world * C) if dist else np.stack([local_e[c] for c in sorted(local_e)])
+        ess = bnr_amd.ess_from_stats(stats_e, nsamp, Lag)
 
     if rank == 0:
         total_chains = world * C
@@ -205,6 +212,8 @@ def main():
                          "avg_launch_us_two_branch_schedule": gram_us_pipe,
                          "peak_measured_microbench": 70.0},
             "max_rhat_gamma": float(np.nanmax(rh[:q])), "max_rhat_xi": float(np.nanmax(rh[q:])),
+            "ess_gamma": None if ess is None else {"min": float(np.nanmin(ess[:q])), "median": float(np.nanmedian(ess[:q])),
+                                                   "draws": int(nsamp * world * C), "min_per_second": float(np.nanmin(ess[:q]) / dt)},
             "counters": counters,
         }
         if single is not None:

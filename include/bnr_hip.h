@@ -147,6 +147,16 @@ int bnr_chain_rhat_stats(bnr_chain *chain, int32_t first_row, int32_t nsamp, dou
 int bnr_chain_summary(bnr_chain *chain, int32_t first_row, int32_t nsamp, int32_t k_lo, int32_t k_hi,
                       double *mean_gamma, double *lower, double *upper, double *prob_xi);
 
+/* Effective sample size -- an ADDITION to the reference (which only has split-Rhat; north-star item "Rhat/ESS check").
+ * bnr_chain_ess_stats: this chain's message over rows first_row .. first_row+nsamp-1: for both halves of the window (the
+ *   halves of split-Rhat) the mean, the variance and the autocovariances at lags 0..max_lag-1 of gamma (q) then xi (V):
+ *   stats[half][2 + max_lag][q + V], computed on the device.
+ * bnr_ess_from_stats: bulk ESS over the messages of all chains ([chain][half][2 + max_lag][nparams]) with the estimator of
+ *   Stan / MCMCDiagnosticTools.ess (split chains, Geyer's initial positive and monotone sequence), truncated at max_lag;
+ *   NaN for a constant parameter.  ess[nparams]. */
+int bnr_chain_ess_stats(bnr_chain *chain, int32_t first_row, int32_t nsamp, int32_t max_lag, double *stats);
+int bnr_ess_from_stats(const double *stats, int32_t nchains, int32_t nparams, int32_t nsamp, int32_t max_lag, double *ess);
+
 /* second half: combine nchains messages (host arrays, chain-major) into Rhat per parameter.  Pure host code.
  * rhat: q+V doubles (gamma first, then xi).  Replaces convergence.jl:49-61. */
 int bnr_rhat_from_stats(const double *stats, int32_t nchains, int32_t nparams, int32_t nsamp, double *rhat);

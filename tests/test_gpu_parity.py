@@ -466,6 +466,33 @@ def test_reference_example_data_through_the_drop_in_api(gpu):
     assert len(str(s).splitlines()) == 3 + 465 + 1 + 30
 
 
+def test_ess_message_and_fit_option(gpu, test1):
+    """bnr_chain_ess_stats (device autocovariances, an addition to the reference): equal to numpy on the fetched table;
+    ChainSet.ess / Fit(ess_max_lag=...) give finite effective sample sizes no larger than N log10 N."""
+    from test_host_cpu import _ess_message
+    X, y = test1
+    tot, first, nsamp, L = 400, 101, 300, 40
+    ch = bnr_amd.Chain(X, y, 5, tot, 11, 1)
+    ch.init_prior()
+    ch.run(2, tot, tot)
+    t = ch.fetch()
+    msg = ch.ess_stats(first, nsamp, L)
+    par = np.concatenate([t["gamma"][first - 1:first - 1 + nsamp, :, 0], t["xi"][first - 1:first - 1 + nsamp, :, 0]], axis=1)
+    ref = _ess_message(par, L)
+    assert msg.shape == ref.shape
+    scale = np.abs(ref).max()
+    assert np.allclose(msg, ref, rtol=1e-9, atol=1e-12 * scale)
+    with pytest.raises(bnr_amd.BnrError):
+        ch.ess_stats(first, nsamp, nsamp)                       # max_lag > nsamp / 2
+    ch.close()
+    r = bnr_amd.Fit(X, y, 5, nburn=300, nsamples=400, psrf_cutoff=50.0, x_transform=False, suppress_timer=True, num_chains=3,
+                    seed=5, filename=None, ess_max_lag=0)
+    n_total = 3 * 400
+    assert r.essgamma.shape == (190,) and r.essxi.shape == (19,)
+    g = r.essgamma[np.isfinite(r.essgamma)]
+    assert g.size > 150 and np.all(g > 1) and np.all(g <= n_total * np.log10(n_total) + 1e-6)
+
+
 def test_bad_arguments_are_reported(gpu):
     X, y, _ = bnr_amd.make_synthetic(8, 4, 2, seed=1)
     with pytest.raises(bnr_amd.BnrError) as e:

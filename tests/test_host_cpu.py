@@ -121,6 +121,69 @@ def test_rhat_from_stats_multichain_equals_oracle_rhat():
     assert r[q] == 1.0
 
 
+def _ess_message(x, L):
+    """numpy restatement of bnr_chain_ess_stats' message for one chain; x: (nsamp, nparams)."""
+    n = x.shape[0]
+    h = n // 2
+    out = []
+    for half in (x[:h], x[n - h:]):
+        m = half.mean(0)
+        c = half - m
+        ac = np.stack([(c[:h - t] * c[t:]).sum(0) / h for t in range(L)])
+        out.append(np.concatenate([m[None], (c * c).sum(0)[None] / (h - 1), ac]))
+    return np.concatenate(out).ravel()
+
+
+def _ess_reference(chains, L):
+    """Independent numpy restatement of the split-chain Geyer estimator (Stan's compute_effective_sample_size), one parameter."""
+    halves = []
+    for x in chains:
+        n = len(x); h = n // 2
+        halves += [x[:h], x[n - h:]]
+    h = len(halves[0]); m = len(halves)
+    means = np.array([v.mean() for v in halves]); vars_ = np.array([v.var(ddof=1) for v in halves])
+    W = vars_.mean(); varp = W * (h - 1) / h + means.var(ddof=1)
+    acov = np.array([[((v - v.mean())[:h - t] * (v - v.mean())[t:]).sum() / h for t in range(L)] for v in halves]).mean(0)
+    rho = 1 - (W - acov) / varp
+    rho[0] = 1.0
+    tau, prev, t = -1.0, np.inf, 0
+    while 2 * t + 1 < L:
+        P = rho[2 * t] + rho[2 * t + 1]
+        if not P > 0:
+            break
+        P = min(P, prev); prev = P; tau += 2 * P; t += 1
+    if 2 * t < L and rho[2 * t] > 0:
+        tau += rho[2 * t]
+    tau = max(tau, 1 / np.log10(m * h))
+    return m * h / tau
+
+
+def test_ess_from_stats_matches_restatement_and_ar1_theory():
+    """bnr_ess_from_stats (an addition to the reference, which only has split-Rhat): equals an independent numpy
+    restatement of the split-chain Geyer estimator and recovers the effective sample size of AR(1) chains,
+    N (1 - phi) / (1 + phi)."""
+    rng = np.random.default_rng(7)
+    nch, n, L = 4, 4000, 200
+    phis = [0.0, 0.5, 0.9, -0.3]
+    x = np.zeros((nch, n, len(phis) + 1))
+    for c in range(nch):
+        for j, phi in enumerate(phis):
+            e = rng.standard_normal(n) * np.sqrt(1 - phi * phi)
+            v = np.empty(n); v[0] = rng.standard_normal()
+            for i in range(1, n):
+                v[i] = phi * v[i - 1] + e[i]
+            x[c, :, j] = v
+        x[c, :, -1] = 3.0                                        # constant parameter -> NaN
+    st = np.stack([_ess_message(x[c], L) for c in range(nch)])
+    ess = bnr_amd.ess_from_stats(st, n, L)
+    assert np.isnan(ess[-1])
+    for j, phi in enumerate(phis):
+        ref = _ess_reference([x[c, :, j] for c in range(nch)], L)
+        assert abs(ess[j] - ref) <= 1e-9 * ref, (phi, ess[j], ref)
+        theory = nch * n * (1 - phi) / (1 + phi)
+        assert 0.75 * theory < ess[j] < 1.3 * theory, (phi, ess[j], theory)
+
+
 def test_lower_triangle_and_setup_X():
     A = np.arange(16.0).reshape(4, 4)
     v = bnr_amd.lower_triangle(A)                            # reads matrix[j,i], j >= i  (utils.jl:50-55)
