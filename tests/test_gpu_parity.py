@@ -493,6 +493,36 @@ def test_ess_message_and_fit_option(gpu, test1):
     assert g.size > 150 and np.all(g > 1) and np.all(g <= n_total * np.log10(n_total) + 1e-6)
 
 
+def test_random_shapes_and_hyperparameters_match_oracle(gpu):
+    """Randomised parity sweep (a fixed-seed slice of tools/fuzz_shapes.py, which was run over 200 cases): random n (incl.
+    the tile-size boundaries 63/64/65, 127/128/129 and n = 1..3), V, R, X flavour and hyper-parameters (incl. aDelta = 0 /
+    bDelta = 0, eta < 1), the chain alone or as the middle member of a lockstep group, against the oracle on identical
+    variates: discrete columns equal, everything else within 1e-6."""
+    rng = np.random.default_rng(12345)
+    for case in range(24):
+        V = int(rng.integers(2, 33)); R = int(rng.integers(1, 13))
+        n = int(rng.choice([1, 2, 3, 31, 33, 63, 64, 65, 100, 127, 128, 129, int(rng.integers(4, 200))]))
+        tot = int(rng.integers(3, 8)); seed = int(rng.integers(1, 10**6)); normal_x = bool(rng.integers(0, 2)); group = bool(rng.integers(0, 2))
+        hyper = dict(eta=float(rng.choice([1.01, 0.5, 2.0])), zeta=float(rng.choice([1.0, 0.3])), iota=float(rng.choice([1.0, 2.5])),
+                     aDelta=float(rng.choice([1.0, 0.0, 3.0])), bDelta=float(rng.choice([1.0, 0.0, 2.0])), nu=float(max(R, rng.choice([10, 12, R + 1]))))
+        X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=seed, normal_x=normal_x)
+        ch = bnr_amd.Chain(X, y, R, tot, seed, 1, **hyper)
+        mates = [bnr_amd.Chain.like(ch, seed, c, tot) for c in (2, 3)] if group else []
+        for c in [ch] + mates:
+            c.init_prior()
+        g = bnr_amd.Group([mates[0], ch, mates[1]]) if group else None
+        (g or ch).run(2, tot, tot)
+        o = bo.Oracle(X, y, R, tot, seed, chain=1, pdf_mode=1, **hyper)
+        o.init_prior()
+        o.run(2, tot, tot)
+        assert_tables_close(ch.fetch(), o.t, what="case %d: n=%d V=%d R=%d group=%s %s" % (case, n, V, R, group, hyper))
+        assert ch.counters()["chol_fail"] == 0
+        if g:
+            g.close()
+        for c in [ch] + mates:
+            c.close()
+
+
 def test_bad_arguments_are_reported(gpu):
     X, y, _ = bnr_amd.make_synthetic(8, 4, 2, seed=1)
     with pytest.raises(bnr_amd.BnrError) as e:
