@@ -958,7 +958,7 @@ __global__ __launch_bounds__(1024) void k_solve_a4(const SRC chain_src)
 //   Psum[b][0] = sum_e S_e ; Psum[b][1+3r+c] = sum_e logpdf(Normal(W_c,e, sqrt(tau2 S_e)), gamma_e)  (gibbs.jl:603-605)
 // Back-projection x_e' a4: one wavefront per column, two columns in flight, a4 in LDS, DPP wave reduction.
 template <class SRC>
-__global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, int flags, int nchains)
+__global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, int flags, int nchains, int nslot)
 {
     // 1-D grid = round_up(blocks, 8) x chains, decoded like k_gram: the workgroups of the group's chains that read the same
     // 32 columns of X are neighbours on the same XCD and share them through its L2
@@ -999,13 +999,13 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
     BNR_BSTAMP(1);
     // update_D! (gibbs.jl:454-458): the rejection attempts of one GIG draw are independent given their counter, so several
     // attempts of every edge are evaluated side by side (half-wave = 32 edges x one attempt) and the first accepted one is
-    // taken -- the same draw as the sequential loop of bnr_gig, in ~1 round instead of 3-5 dependent ones.  One chain: all
-    // four waves (attempts 8 r + 0..7), the block is latency-bound; lockstep group: wave 0 only (attempts 2 r + 0..1), the
-    // launch is throughput-bound and speculative attempts that are thrown away cost what they save.
+    // taken -- the same draw as the sequential loop of bnr_gig, in ~1 round instead of 3-5 dependent ones.  nslot (host) = 8
+    // while the launch is latency-bound (few blocks: one chain at moderate q; all four waves, attempts 8 r + 0..7), 2 when
+    // it is throughput-bound (a lockstep group, or q large: wave 0 only) -- speculative attempts that are thrown away then
+    // cost what they save (n=500, V=300: 58 vs 46 us per launch with 8 slots).
     __shared__ double s_val[8][32];
     __shared__ int s_acc[8][32];
     int cap = 0;
-    const int nslot = nchains == 1 ? 8 : 2;
     if (2 * wave >= nslot) return;
     const int el32 = lane & 31, slot = wave * 2 + (lane >> 5);
     const int e = e0 + el32;
