@@ -176,12 +176,14 @@ def main():
 
     # convergence check over all chains of the job: RCCL all-gather of the per-chain split-Rhat messages
     nsamp = K
-    local = {cid: ch.rhat_stats(W + 2, nsamp) for cid, ch in zip(ids, chains)}
-    if dist:
-        stats = bnr_amd.allgather_stats(local, world * C)
-    else:
-        stats = np.stack([local[c] for c in sorted(local)])
-    rh = bnr_amd.rhat_from_stats(stats, nsamp)
+    rh = None
+    if nsamp >= 4:                                               # split-Rhat needs two samples per half
+        local = {cid: ch.rhat_stats(W + 2, nsamp) for cid, ch in zip(ids, chains)}
+        if dist:
+            stats = bnr_amd.allgather_stats(local, world * C)
+        else:
+            stats = np.stack([local[c] for c in sorted(local)])
+        rh = bnr_amd.rhat_from_stats(stats, nsamp)
     # effective sample size of the timed window over all chains (an addition to the reference's Rhat; same exchange pattern)
     ess = None
     if nsamp >= 64:
@@ -211,7 +213,7 @@ def main():
                          "flops_per_launch": flops_gram, "avg_launch_us": gram_us, "launches_timed": gram_n,
                          "avg_launch_us_two_branch_schedule": gram_us_pipe,
                          "peak_measured_microbench": 70.0},
-            "max_rhat_gamma": float(np.nanmax(rh[:q])), "max_rhat_xi": float(np.nanmax(rh[q:])),
+            "max_rhat_gamma": None if rh is None else float(np.nanmax(rh[:q])), "max_rhat_xi": None if rh is None else float(np.nanmax(rh[q:])),
             "ess_gamma": None if ess is None else {"min": float(np.nanmin(ess[:q])), "median": float(np.nanmedian(ess[:q])),
                                                    "draws": int(nsamp * world * C), "min_per_second": float(np.nanmin(ess[:q]) / dt)},
             "counters": counters,
