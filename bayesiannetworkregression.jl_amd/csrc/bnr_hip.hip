@@ -431,14 +431,17 @@ static void launch_rhs(bnr_exec &x, int s) { BNR_LAUNCH(k_rhs, dim3(x.shape->n_p
 static void launch_chol(bnr_exec &x, int s, hipStream_t st)
 {
     const int nbk = x.shape->n_pad / BNR_NB;
-    // update workgroups take `tpw` blocks each, chosen per panel so that panels + updates of all members fit the chip in
-    // one round (two 256-thread workgroups per CU): one block each while they are few, up to eight for large n or groups
+    // update workgroups: one 32 x 32 block each while panels + updates of all members fit the chip in one round (two 256-thread
+    // workgroups per CU); otherwise (large n, groups) 64 x 64 super blocks
     const int ncu = x.ncu;
     for (int p = 0; p < nbk; ++p) {
         const int npan = bnr_chol_npanel(nbk, p), ntile = bnr_chol_ntile(nbk, p);
         const int room = std::max(64, 2 * ncu - x.nb * npan);
-        const int tpw = std::min(8, std::max(1, (x.nb * ntile + room - 1) / room));
-        BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + (ntile + tpw - 1) / tpw), dim3(256), 0, st, x, p, s, tpw);
+        if (x.nb * ntile > room) {                       // many blocks: 64 x 64 super blocks, one 32 x 32 block per wave
+            BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + bnr_chol_nsuper(nbk, p)), dim3(256), 0, st, x, p, s, 0);
+        } else {
+            BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + ntile), dim3(256), 0, st, x, p, s, 1);
+        }
     }
 }
 static void launch_solve(bnr_exec &x)
