@@ -578,8 +578,9 @@ def test_headline_size_properties(gpu):
     o.init_prior()
     o.run(2, 4, 4)
     assert_tables_close(A, o.t, rows_got=slice(0, 4), what="headline first rows")
-    # the same chain as member of a lockstep group of three (blockIdx.z path of every kernel at the full size)
-    members = [bnr_amd.Chain.like(a, 20240501, cid, tot) for cid in (2, 1, 3)]
+    # the same chain as member of a lockstep group of five (blockIdx.z path of every kernel at the full size; with five
+    # members the trailing update of the factorization runs in its 64 x 64 super-block form, alone in its 32 x 32 form)
+    members = [bnr_amd.Chain.like(a, 20240501, cid, tot) for cid in (2, 1, 3, 4, 5)]
     for m in members:
         m.init_prior()
     grp = bnr_amd.Group(members)
