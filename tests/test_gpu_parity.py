@@ -52,6 +52,7 @@ def test1():
 CASES = [  # n, V, R, rows, normal_x   (ragged n vs the 64-row tiles, tiny V, R = 1, R > V ...)
     (40, 8, 3, 12, False), (70, 19, 5, 30, True), (1, 2, 1, 6, False), (3, 2, 4, 6, True), (65, 5, 2, 8, False),
     (129, 12, 7, 8, True), (200, 50, 5, 10, False), (64, 33, 10, 6, True),
+    (1000, 10, 3, 5, True),      # 32 factorization panels; the trailing update runs in its 64 x 64 super-block form
 ]
 
 
