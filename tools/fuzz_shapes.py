@@ -7,15 +7,16 @@ from oracle import bnr_oracle as bo
 N = int(sys.argv[1]); rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst_all = 0.0
 for case in range(N):
-    V = int(rng.integers(2, 41)); R = int(rng.integers(1, 13)); n = int(rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200, int(rng.integers(4, 260))]))
+    V = int(rng.integers(2, 41)); R = int(rng.integers(1, 13)); n = int(rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200, int(rng.integers(4, 260)), int(rng.integers(260, 700))]))
     tot = int(rng.integers(3, 9)); seed = int(rng.integers(1, 10**6)); normal_x = bool(rng.integers(0, 2)); group = bool(rng.integers(0, 2))
     hyper = dict(eta=float(rng.choice([1.01, 0.5, 2.0])), zeta=float(rng.choice([1.0, 0.3])), iota=float(rng.choice([1.0, 2.5])),
                  aDelta=float(rng.choice([1.0, 0.0, 3.0])), bDelta=float(rng.choice([1.0, 0.0, 2.0])), nu=float(max(R, rng.choice([10, 12, R + 1]))))
     X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=seed, normal_x=normal_x)
     ch = bnr_amd.Chain(X, y, R, tot, seed, 1, **hyper)
-    mates = [bnr_amd.Chain.like(ch, seed, c, tot) for c in (2, 3)] if group else []
+    gsize = int(rng.integers(2, 8))
+    mates = [bnr_amd.Chain.like(ch, seed, c, tot) for c in range(2, gsize + 1)] if group else []
     for c in [ch] + mates: c.init_prior()
-    g = bnr_amd.Group([mates[0], ch, mates[1]]) if group else None
+    g = bnr_amd.Group(mates[:1] + [ch] + mates[1:]) if group else None
     (g or ch).run(2, tot, tot)
     got = ch.fetch()
     o = bo.Oracle(X, y, R, tot, seed, chain=1, pdf_mode=1, **hyper); o.init_prior(); o.run(2, tot, tot)
