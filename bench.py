@@ -88,12 +88,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # rehearsal of the multi-rank path on a one-GPU box: every rank uses device 0, the exchanges run over gloo
+    one_dev = os.environ.get("BNR_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     if a.gpus > 1 or world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_dev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
+    red_dev = "cpu" if one_dev else "cuda"               # where the max-over-ranks of the timings is reduced
 
     cfg = CONFIGS[a.config]
     n, V, R = cfg["n"], cfg["V"], cfg["R"]
@@ -135,7 +143,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -168,7 +176,7 @@ def main():
         torch.cuda.synchronize()
         dts = time.perf_counter() - t1
         if dist:
-            t = torch.tensor([dts], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dts], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dts = float(t.item())
         single = {"value": world * Ks / dts, "unit": "iterations/s", "chains_per_gpu": 1, "steps": Ks, "ms_per_step": 1e3 * dts / Ks}

@@ -524,6 +524,34 @@ def test_random_shapes_and_hyperparameters_match_oracle(gpu):
             c.close()
 
 
+def test_bench_multi_rank_path_rehearsal(gpu):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed with two ranks on
+    this one GPU (BNR_BENCH_ONE_DEVICE=1: both ranks use device 0, exchanges over gloo instead of RCCL): rank 0 prints ONE
+    JSON line whose value aggregates the chains of both ranks."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BNR_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "8",
+           "--chains-per-gpu", "2", "--config", "cfg2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["warmup"] == 8 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert "4 chains total" in d["config"]["workload"] and d["value"] > 0 and d["roofline"]["achieved"] > 0
+    assert abs(d["value"] - 4 * 40 / (d["ms_per_step"] * 40 / 1e3)) < 1e-6 * d["value"]
+    assert d["counters"]["chol_fail"] == 0 and d["single_chain"]["value"] > 0
+
+
 def test_bad_arguments_are_reported(gpu):
     X, y, _ = bnr_amd.make_synthetic(8, 4, 2, seed=1)
     with pytest.raises(bnr_amd.BnrError) as e:
