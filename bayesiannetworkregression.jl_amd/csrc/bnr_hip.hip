@@ -140,6 +140,24 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     if (!out || !hyper || (!donor && (!X || !y))) return fail(BNR_ERR_BAD_ARG, "NULL argument");
     if (n < 1 || V < 2 || R < 1 || R > BNR_RMAX || tot_save < 2)
         return fail(BNR_ERR_BAD_ARG, "need n>=1, V>=2, 1<=R<=32, tot_save>=2");
+    // LDS budgets of the kernels that stage a whole vector / the R x V matrix u: k_tail keeps u (R V doubles) next to 33 KiB of
+    // static arrays, k_backproj / k_solve_a4 keep an n-vector; 160 KiB per workgroup on gfx950
+    if ((size_t)R * V > 15360) return fail(BNR_ERR_BAD_ARG, "R*V must not exceed 15360 (u is staged in LDS by the scalar tail kernel)");
+    if (n > 14000) return fail(BNR_ERR_BAD_ARG, "n must not exceed 14000 (n-vectors are staged in LDS)");
+    {
+        static bool lds_attr_set = false;                 // dynamic LDS beyond 64 KiB needs the attribute (once per process)
+        if (!lds_attr_set) {
+            const int big = 124 * 1024;
+            hipFuncSetAttribute((const void *)&k_tail<bnr_one>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            hipFuncSetAttribute((const void *)&k_tail<bnr_many>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            hipFuncSetAttribute((const void *)&k_backproj<bnr_one>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            hipFuncSetAttribute((const void *)&k_backproj<bnr_many>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            hipFuncSetAttribute((const void *)&k_solve_a4<bnr_one>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            hipFuncSetAttribute((const void *)&k_solve_a4<bnr_many>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipGetLastError();
+            lds_attr_set = true;
+        }
+    }
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(BNR_ERR_BAD_ARG, "no such device");

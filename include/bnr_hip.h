@@ -55,7 +55,8 @@ int bnr_device_count(int *count);
 
 /* Allocate a chain: copies X (n x q col-major) and y to HBM, allocates the tot_save-row state table and all
  * work space on `device`.  Replaces the allocation half of initialize_and_run! (gibbs.jl:822-841).
- * The RNG stream is keyed by seed + chain_id (the reference's Xoshiro(seed+c), gibbs.jl:928). */
+ * The RNG stream is keyed by seed + chain_id (the reference's Xoshiro(seed+c), gibbs.jl:928).
+ * Limits (BNR_ERR_BAD_ARG otherwise): 1 <= R <= 32, V >= 2, R*V <= 15360, n <= 14000 (LDS budgets of single-workgroup kernels). */
 int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const double *y, const bnr_hyper *hyper,
                      uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save, bnr_chain **out);
 /* Another chain of the same fit on the same device: same X, y, sizes and hyper-parameters as `donor`, own seed /

@@ -552,6 +552,26 @@ def test_bench_multi_rank_path_rehearsal(gpu):
     assert d["counters"]["chol_fail"] == 0 and d["single_chain"]["value"] > 0
 
 
+def test_shapes_at_the_lds_budgets(gpu):
+    """u (R x V) and the n-vectors are staged in LDS by single workgroups: shapes that need more than the default 64 KiB of
+    dynamic LDS run (R V = 9600: 75 KiB in k_tail; R = 32 is the latent-dimension limit), shapes beyond the 160 KiB of the
+    CU are rejected at bnr_chain_create with a message instead of failing at a launch."""
+    X, y, _ = bnr_amd.make_synthetic(20, 300, 32, seed=1)
+    ch = bnr_amd.Chain(X, y, 32, 4, 1, 1, nu=34)                # the inverse Wishart needs nu >= R
+    ch.init_prior()
+    ch.run(2, 4, 4)
+    t = ch.fetch()
+    assert all(np.all(np.isfinite(t[k])) for k in bo.COLUMNS)
+    c = ch.counters()
+    assert c["chol_fail"] == 0 and c["nan_w"] == 0
+    ch.close()
+    Xb, yb, _ = bnr_amd.make_synthetic(5, 600, 32, seed=1)
+    with pytest.raises(bnr_amd.BnrError, match="R\\*V must not exceed"):
+        bnr_amd.Chain(Xb, yb, 32, 4, 1, 1, nu=34)
+    with pytest.raises(bnr_amd.BnrError, match="n must not exceed"):
+        bnr_amd.Chain(np.zeros((14001, 3), order="F"), np.zeros(14001), 2, 4, 1, 1)
+
+
 def test_bad_arguments_are_reported(gpu):
     X, y, _ = bnr_amd.make_synthetic(8, 4, 2, seed=1)
     with pytest.raises(bnr_amd.BnrError) as e:
