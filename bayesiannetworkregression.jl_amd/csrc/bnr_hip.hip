@@ -1,6 +1,7 @@
 // bnr_hip.hip -- C ABI (include/bnr_hip.h) over the gfx950 kernels in bnr_kernels.h.
-// Host side of one chain: allocation, the run! loop with the purge ring (gibbs.jl:849-864), the test hooks that
-// mirror the reference's update_*! functions, table fetch/load and the split-Rhat reduction.
+// Host side: chain allocation (own or shared device inputs), the run! loop with the purge ring (gibbs.jl:849-864) for one
+// chain or for a lockstep group of chains (one launch per kernel for all members), the test hooks that mirror the
+// reference's update_*! functions, table fetch/load, the split-Rhat / ESS messages and the device-side Summary.
 #include "../../include/bnr_hip.h"
 #include "bnr_kernels.h"
 

@@ -178,7 +178,11 @@ int bnr_chain_debug_time_gram(bnr_chain *chain, int32_t reps, double *avg_us);
 /* diagnostics: copy an internal work buffer to the host (0 = factorization matrix E, 1 = rhs b, 2 = a4, 3 = Gram partials) */
 int bnr_chain_debug_copy(bnr_chain *chain, int32_t which, double *out, int64_t count);
 
-/* tunables (performance only; never change results): name = "gram_ksplit", "graph", "overlap" ... */
+/* tunables (performance only; never change results):
+ *   "graph"     1 (default): replay captured hipGraphs of graph_k sweeps; 0: launch every kernel eagerly
+ *   "graph_k"   sweeps per captured graph (default 8)
+ *   "overlap"   1 (default): scalar branch and Gram/factorization branch of a sweep on two streams; 0: one stream
+ *   "profiling" 1: record HIP events around every k_gram launch (forces eager launches), see bnr_chain_last_timing */
 int bnr_chain_set_option(bnr_chain *chain, const char *name, int64_t value);
 
 /* Host-side copies of the draw-site primitives (same source as the device functions), exported so that the
