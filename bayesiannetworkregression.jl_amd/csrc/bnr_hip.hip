@@ -457,9 +457,14 @@ static void launch_chol(bnr_exec &x, int s, hipStream_t st)
         const int npan = bnr_chol_npanel(nbk, p), ntile = bnr_chol_ntile(nbk, p);
         const int room = std::max(64, 2 * ncu - x.nb * npan);
         if (x.nb * ntile > room) {                       // many blocks: 64 x 64 super blocks, one 32 x 32 block per wave
-            BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + bnr_chol_nsuper(nbk, p)), dim3(256), 0, st, x, p, s, 0);
+            const int nsup = bnr_chol_nsuper(nbk, p);
+            // ... and as many of them per workgroup as it takes to keep the update workgroups on the CUs the panels leave
+            // free (at most 4: they must stay shorter than a panel sweep)
+            const int freecu = ncu - x.nb * npan;
+            const int spw = freecu > 0 ? std::min(4, std::max(1, (x.nb * nsup + freecu - 1) / freecu)) : 1;
+            BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + (nsup + spw - 1) / spw), dim3(256), 0, st, x, p, s, 0, spw);
         } else {
-            BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + ntile), dim3(256), 0, st, x, p, s, 1);
+            BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + ntile), dim3(256), 0, st, x, p, s, 1, 1);
         }
     }
 }

@@ -785,7 +785,7 @@ __device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &
     return bad;
 }
 template <class SRC>
-__global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p, int s, int tpw)
+__global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p, int s, int tpw, int spw)
 {
     const bnr_dev &cd = chain_src.get_x();               // grid = (chains, workgroups): blockIdx.x = chain, blockIdx.y = workgroup
     __shared__ bnr_panel_lds sh;
@@ -803,51 +803,56 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
             // large trailing matrix: one workgroup per 64 x 64 super block (2 x 2 blocks), one 32 x 32 block per wave as
             // 2 x 2 MFMA tiles -- half the fragment loads per MFMA and a quarter of the workgroups; every element still sees
             // the same eight MFMA steps in the same order, so the result is bitwise that of the small-block path
-            const int ms = (m + 1) / 2, ntri = ms * (ms + 1) / 2;
-            int t = (int)blockIdx.y - npanel, R0, C0;
-            bool ident = false;
-            if (t < ntri) {
-                int ti = 0;
-                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-                int tj = t - ti * (ti + 1) / 2;
-                R0 = p + 1 + 2 * ti; C0 = p + 1 + 2 * tj;
-            } else {
-                t -= ntri;
-                const int ps = (p + 1) / 2;
-                C0 = p + 1 + 2 * (t / ps); R0 = nbk + 2 * (t % ps);
-                ident = true;
-            }
-            const int rho = R0 + (wave >> 1), j = C0 + (wave & 1);
-            const bool ok = j < nbk && (ident ? (rho - nbk < p) : (rho < nbk && rho >= j));
-            if (!ok) return;
-            double *cp = E + (size_t)(rho * BNR_NB + ln) + ld * (size_t)(j * BNR_NB + lq);
-            bnr_d4 c[2][2];                                   // [column tile][row tile]
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) c[a][b][r] = cp[(size_t)(16 * b) + ld * (size_t)(16 * a + 4 * r)];
-            const double *colrows = E + (size_t)(j * BNR_NB) + ld * (size_t)kc, *rowrows = E + (size_t)(rho * BNR_NB) + ld * (size_t)kc;
-            double av[2][8], bv[2][8];
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const size_t o = (size_t)ln + ld * (size_t)(4 * ks + lq);
-                av[0][ks] = colrows[o]; av[1][ks] = colrows[o + 16];
-                bv[0][ks] = rowrows[o]; bv[1][ks] = rowrows[o + 16];
-            }
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
+            const int ms = (m + 1) / 2, ntri = ms * (ms + 1) / 2, nsup = bnr_chol_nsuper(nbk, p);
+            // spw super blocks per workgroup (host: as many as it takes for the update workgroups to fit the CUs the panel
+            // workgroups leave free -- a sweeping wave that shares its SIMD with MFMA work of another workgroup runs 20 % slower)
+            for (int u = 0; u < spw; ++u) {
+                int t = ((int)blockIdx.y - npanel) * spw + u, R0, C0;
+                if (t >= nsup) break;
+                bool ident = false;
+                if (t < ntri) {
+                    int ti = 0;
+                    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+                    int tj = t - ti * (ti + 1) / 2;
+                    R0 = p + 1 + 2 * ti; C0 = p + 1 + 2 * tj;
+                } else {
+                    t -= ntri;
+                    const int ps = (p + 1) / 2;
+                    C0 = p + 1 + 2 * (t / ps); R0 = nbk + 2 * (t % ps);
+                    ident = true;
+                }
+                const int rho = R0 + (wave >> 1), j = C0 + (wave & 1);
+                const bool ok = j < nbk && (ident ? (rho - nbk < p) : (rho < nbk && rho >= j));
+                if (!ok) continue;
+                double *cp = E + (size_t)(rho * BNR_NB + ln) + ld * (size_t)(j * BNR_NB + lq);
+                bnr_d4 c[2][2];                                   // [column tile][row tile]
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) c[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[a][ks], bv[b][ks], c[a][b], 0, 0, 0);
+                    for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+                        for (int r = 0; r < 4; ++r) c[a][b][r] = cp[(size_t)(16 * b) + ld * (size_t)(16 * a + 4 * r)];
+                const double *colrows = E + (size_t)(j * BNR_NB) + ld * (size_t)kc, *rowrows = E + (size_t)(rho * BNR_NB) + ld * (size_t)kc;
+                double av[2][8], bv[2][8];
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int ks = 0; ks < 8; ++ks) {
+                    const size_t o = (size_t)ln + ld * (size_t)(4 * ks + lq);
+                    av[0][ks] = colrows[o]; av[1][ks] = colrows[o + 16];
+                    bv[0][ks] = rowrows[o]; bv[1][ks] = rowrows[o + 16];
+                }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) cp[(size_t)(16 * b) + ld * (size_t)(16 * a + 4 * r)] = c[a][b][r];
+                for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) c[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[a][ks], bv[b][ks], c[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) cp[(size_t)(16 * b) + ld * (size_t)(16 * a + 4 * r)] = c[a][b][r];
+            }
             return;
         }
         // few blocks: tpw of them per workgroup, each wave one 16 x 16 tile of every block
