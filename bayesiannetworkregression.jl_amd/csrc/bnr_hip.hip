@@ -459,9 +459,10 @@ static void launch_chol(bnr_exec &x, int s, hipStream_t st)
         if (x.nb * ntile > room) {                       // many blocks: 64 x 64 super blocks, one 32 x 32 block per wave
             const int nsup = bnr_chol_nsuper(nbk, p);
             // ... and as many of them per workgroup as it takes to keep the update workgroups on the CUs the panels leave
-            // free (at most 4: they must stay shorter than a panel sweep)
+            // free (at most 4: they must stay shorter than a panel sweep; only while E is L2-sized -- for large n the update is
+            // bandwidth-bound and wants every workgroup in flight at once: n=2000 408 vs 421 it/s)
             const int freecu = ncu - x.nb * npan;
-            const int spw = freecu > 0 ? std::min(4, std::max(1, (x.nb * nsup + freecu - 1) / freecu)) : 1;
+            const int spw = (freecu > 0 && nbk <= 24) ? std::min(4, std::max(1, (x.nb * nsup + freecu - 1) / freecu)) : 1;
             BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + (nsup + spw - 1) / spw), dim3(256), 0, st, x, p, s, 0, spw);
         } else {
             BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + ntile), dim3(256), 0, st, x, p, s, 1, 1);
