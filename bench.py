@@ -68,6 +68,21 @@ def cpu_baseline(n, V, R, seed, nchains, budget_s=15.0):
                        "OpenMP threads each" % (nchains, budget_s, its, per))
 
 
+class _StdoutToStderr:
+    """RCCL prints a banner (ROCm version, hostname, library path) on STDOUT when its first communicator is created; the
+    contract of this script is ONE JSON line on stdout, so file descriptor 1 points at stderr while that happens."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,10 +111,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        if one_dev:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        with _StdoutToStderr():
+            if one_dev:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            torch.cuda.set_device(local_rank)
+            dist.barrier()                                # creates the communicator (and its banner) now, not in the timed region
     torch.cuda.set_device(local_rank)
     red_dev = "cpu" if one_dev else "cuda"               # where the max-over-ranks of the timings is reduced
 
