@@ -246,7 +246,7 @@ def main():
         }
         if single is not None:
             out["single_chain"] = single
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:            # the host-core baseline is taken at N = 1 only
             out["cpu_baseline"] = cpu_baseline(n, V, R, a.seed, C)
         print(json.dumps(out))
     for ch in chains:
