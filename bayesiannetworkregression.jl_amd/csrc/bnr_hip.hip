@@ -180,7 +180,7 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
         int ncu = 256;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
         const char *ev = getenv("BNR_GRAM_KG");
-        d.gram_kg = (ev && atoi(ev) == 4) ? 4 : ((ev && atoi(ev) == 1) ? 1 : 2);
+        d.gram_kg = (ev && atoi(ev) == 4) ? 4 : 2;
         auto best_split = [&](int slots) {
             double best = -1.0;
             int bk = 1;
@@ -436,10 +436,7 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
         hipEventRecord(e0, st);
     }
     const dim3 ggrid(round_up(ntl * d.ksplit, 8) * x.nb);
-    if (d.gram_kg == 1) {                                 // experiment: one K-group per workgroup (4 waves per barrier domain)
-        if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 1>), ggrid, dim3(256), 0, st, bnr_one{d}, s, 1);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_many, 1>), ggrid, dim3(256), 0, st, bnr_many{x.cds}, s, x.nb);
-    } else if (d.gram_kg == 4) {
+    if (d.gram_kg == 4) {
         if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), ggrid, dim3(1024), 0, st, bnr_one{d}, s, 1);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_many, 4>), ggrid, dim3(1024), 0, st, bnr_many{x.cds}, s, x.nb);
     } else {

@@ -570,8 +570,7 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
 #pragma unroll
     for (int idx = threadIdx.x; idx < BNR_GT * BNR_GT; idx += KG * 256) {
         if (KG == 4) out[idx] = (sred[idx] + sred[BNR_GT * BNR_GT + idx]) + (sred[2 * BNR_GT * BNR_GT + idx] + sred[3 * BNR_GT * BNR_GT + idx]);
-        else if (KG == 2) out[idx] = sred[idx] + sred[BNR_GT * BNR_GT + idx];
-        else out[idx] = sred[idx];
+        else out[idx] = sred[idx] + sred[BNR_GT * BNR_GT + idx];
     }
     BNR_GSTAMP(3);
 }
