@@ -1246,15 +1246,12 @@ static void launch_gram_only(bnr_chain *c)
 }
 int bnr_chain_debug_time_gram(bnr_chain *c, int32_t reps, double *avg_us)
 {
-    if (!c || !avg_us || reps < 1) return fail(BNR_ERR_BAD_ARG, "bad argument");
-    int gridsz = 0;
-    if (reps >= 1000000) { gridsz = reps / 1000000; reps = reps % 1000000; }
+    if (!c || !avg_us || reps < 1 || reps > 100000) return fail(BNR_ERR_BAD_ARG, "bad argument");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->x.stream));
     c->plan_pin[0] = bnr_plan_entry{1u, 1, 0, 0};
     int rc = upload_plan(c, 1);
     if (rc) return rc;
-    const bnr_dev &d = c->d;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int w = 0; w < 3; ++w) launch_gram_only(c);

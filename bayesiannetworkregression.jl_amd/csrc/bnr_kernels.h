@@ -1044,6 +1044,18 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
 #define BNR_BSTAMP(slot) do { } while (0)
 #endif
     BNR_BSTAMP(0);
+    // u[r,l] u[r,k] of this block's edges for the Lambda log-likelihoods at the end: requested now, so that the dependent
+    // global loads (edge -> nodes -> u) are in flight behind the dot products instead of in front of the final sums
+    __shared__ double sdr[BNR_RMAX * 33];
+    if (flags & 4) {
+        const double *un0 = row + cd.o_u;
+        for (int idx = tid; idx < R * 32; idx += blockDim.x) {
+            const int r = idx >> 5, ee = idx & 31;
+            double v = 0.0;
+            if (ee < ne) { const int l0 = cd.el[e0 + ee], k0 = cd.ek[e0 + ee]; v = un0[r + R * l0] * un0[r + R * k0]; }
+            sdr[r * 33 + ee] = v;
+        }
+    }
     if (flags & 1) {
         for (int i = tid; i < cd.n_pad; i += blockDim.x) sa[i] = cd.a4[i];
         __syncthreads();
@@ -1074,9 +1086,8 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
     const int e = e0 + el32;
     const bool act = el32 < ne;
     double gam = 0.0, Snew = 1.0, W = 0.0;
-    int l = 0, k = 0;
     if (act) {
-        W = cd.Wbuf[e]; l = cd.el[e]; k = cd.ek[e];
+        W = cd.Wbuf[e];
         if (flags & 1) {
             double Sp = prev[cd.o_S + e];
             gam = tau * (cd.sz[e] + Sp * sdot[el32]) + W;
@@ -1113,12 +1124,12 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
     // per-edge terms go through LDS ([term][lane], lane-contiguous) and lane j then sums term j over the 32 edges in a
     // fixed order: one pass instead of 3R+1 wave reductions
     double *st = sh;                                  // reuse the a4 staging area: (3R + 1) x 33 doubles <= n_pad + 64
-    const double *un = row + cd.o_u, *lamp = prev + cd.o_lam;
+    const double *lamp = prev + cd.o_lam;
     const double sd = sqrt(tau2 * Snew), lsd = log(sd) + 0.5 * log(2.0 * BNR_PI);
     if (lane < 32) {
         st[lane] = act ? Snew : 0.0;
         for (int r = 0; r < R; ++r) {
-            double dr = act ? un[r + R * l] * un[r + R * k] : 0.0;
+            double dr = sdr[r * 33 + lane];
             double lr = lamp[r];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
