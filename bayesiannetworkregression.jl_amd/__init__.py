@@ -6,5 +6,5 @@ from ._build import build, LIB                                    # noqa: F401
 from ._capi import BnrError, Chain, Group, device_count, ess_from_stats, new_table, rhat_from_stats, lib, EXPORTS   # noqa: F401
 from .api import (BNRSummary, ChainSet, Fit, Results, Summary, create_lower_tri, device_summary, generate_samples,   # noqa: F401
                   generate_samples_dbl, initialize_and_run, lower_triangle, return_psrf_VOI, run, setup_X,
-                  allgather_stats, local_chain_ids)
+                  allgather_stats, local_chain_ids, shared_seed)
 from .synthetic import make_synthetic                             # noqa: F401

@@ -40,6 +40,8 @@ _SIGS = {
                                 C.POINTER(C.c_int32)]),
     "bnr_chain_run_async": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "bnr_chain_sync": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "bnr_chain_prepare": (C.c_int, [C.c_void_p]),
+    "bnr_group_prepare": (C.c_int, [C.c_void_p]),
     "bnr_group_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]),
     "bnr_group_destroy": (C.c_int, [C.c_void_p]),
     "bnr_group_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, PROGRESS_CB, C.c_void_p,
@@ -174,6 +176,10 @@ class Chain:
                                    None, C.byref(nxt)))
         return nxt.value
 
+    def prepare(self):
+        """Capture the hipGraphs the run loop replays now (otherwise done lazily by the first run call)."""
+        check(self.L.bnr_chain_prepare(self.h))
+
     def run_async(self, first_index, nburn, total, purge_burn=None):
         check(self.L.bnr_chain_run_async(self.h, first_index, nburn, total, purge_burn or 0))
 
@@ -302,6 +308,9 @@ class Group:
         check(self.L.bnr_group_run(self.h, first_index, nburn, total, purge_burn or 0, prog_freq if callback else 0, cb,
                                    None, C.byref(nxt)))
         return nxt.value
+
+    def prepare(self):
+        check(self.L.bnr_group_prepare(self.h))
 
     def set_option(self, name, value):
         check(self.L.bnr_group_set_option(self.h, name.encode(), int(value)))

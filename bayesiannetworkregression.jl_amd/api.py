@@ -180,6 +180,24 @@ def _default_device():
     return int(os.environ.get("LOCAL_RANK", "0")) if _dist() else 0
 
 
+def shared_seed(seed, draw):
+    """The ONE seed of a fit: the reference draws it once and keys chain c with seed + c (gibbs.jl:739, 928).  With chains
+    sharded over torch.distributed ranks the draw happens on rank 0 and is broadcast -- independent draws per rank could put
+    two chains on the same stream (s_a + c_a == s_b + c_b) and would make parameters.log's seed describe rank 0 only."""
+    d = _dist()
+    if seed is not None and d is None:
+        return int(seed)
+    value = int(draw()) if seed is None else int(seed)
+    if d is None:
+        return value
+    import torch
+    use_cuda = d.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+    t = torch.tensor([value], dtype=torch.int64, device=dev)
+    d.broadcast(t, src=0)
+    return int(t.item())
+
+
 def allgather_stats(local_stats, num_chains):
     """All-gather of the per-chain split-Rhat messages (4*(q+V) doubles each).  local_stats: {chain_id: array}.
     Returns (num_chains, 4*(q+V)) in chain order on every rank.  With torch.distributed on GPUs this is one RCCL
@@ -355,7 +373,7 @@ def generate_samples(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1
     prog_freq = 1000
     if prog_freq >= nburn:
         prog_freq = 10
-    seed_eff = random.SystemRandom().randrange(1, 2**31) if seed is None else seed      # Xoshiro() when seed===nothing
+    seed_eff = shared_seed(seed, lambda: random.SystemRandom().randrange(1, 2**31))     # Xoshiro() when seed===nothing; one draw per fit
     purge_burn = _normalize_purge(purge_burn, nburn)
     tot_save = total if purge_burn is None else nsamp + purge_burn
     hyper = dict(eta=eta, zeta=zeta, iota=iota, aDelta=aDelta, bDelta=bDelta, nu=nu)
@@ -411,7 +429,7 @@ def generate_samples_dbl(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDel
     prog_freq = 1000
     if prog_freq >= nburn:
         prog_freq = 10
-    seed_eff = random.SystemRandom().randrange(1, 2**31) if seed is None else seed
+    seed_eff = shared_seed(seed, lambda: random.SystemRandom().randrange(1, 2**31))
     purge_burn = _normalize_purge(purge_burn, nburn)
     tot_save = total if purge_burn is None else nsamp + purge_burn
     hyper = dict(eta=eta, zeta=zeta, iota=iota, aDelta=aDelta, bDelta=bDelta, nu=nu)
@@ -461,7 +479,7 @@ def Fit(X, y, R, eta=1.01, V=30, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1.0, nu=
     Extensions: summary_interval=95 computes Summary's statistics on the GPU (Results.summary_device);
     return_state=False then leaves the (large) state table on the device and frees it; ess_max_lag=0 (default lag
     window) or a lag count adds bulk effective sample sizes over all chains (Results.essgamma / essxi)."""
-    seed = random.randrange(1, 55556) if seed is None else seed           # sample(1:55555) :739
+    seed = shared_seed(seed, lambda: random.randrange(1, 55556))          # sample(1:55555) :739; drawn on rank 0, the same on every rank
     if _rank_world()[0] == 0 and filename:
         with open(filename, "w") as f:
             f.write("BayesianNetworkRegression.jl Fit! function\n")

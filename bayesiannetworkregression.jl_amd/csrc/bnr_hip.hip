@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -35,8 +36,9 @@ struct bnr_exec {
     size_t fj_next = 0;
     int overlap = 1;
     int use_graph = 1, graph_k = 8;
-    hipGraphExec_t gexec = nullptr;
-    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr, gexec1 = nullptr;   // graph_k sweeps / ONE sweep (the remainder of a batch is replayed too)
+    hipGraph_t graph = nullptr, graph1 = nullptr;
+    int64_t n_replayed = 0, n_eager = 0;                // sweeps issued by graph replay / eagerly since the last run call began
     // profiling
     int profiling = 0;
     std::vector<hipEvent_t> ev;  // pairs around k_gram
@@ -92,6 +94,23 @@ static void forget_alloc(bnr_chain *c, void *p)
     if (it != c->allocs.end()) c->allocs.erase(it);
 }
 
+// Dynamic LDS beyond 64 KiB needs the function attribute, and the attribute is per DEVICE: set once per device of this
+// process, after hipSetDevice, under a lock (handles may be created from several host threads); failures are reported at create.
+static int ensure_lds_attributes(int device)
+{
+    static std::mutex mu;
+    static std::vector<char> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if ((int)done.size() <= device) done.resize(device + 1, 0);
+    if (done[device]) return BNR_OK;
+    const int big = 124 * 1024;
+    const void *fns[] = {(const void *)&k_tail<bnr_one>, (const void *)&k_tail<bnr_many>, (const void *)&k_backproj<bnr_one>,
+                         (const void *)&k_backproj<bnr_many>, (const void *)&k_solve_a4<bnr_one>, (const void *)&k_solve_a4<bnr_many>};
+    for (const void *f : fns) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    done[device] = 1;
+    return BNR_OK;
+}
+
 extern "C" {
 
 static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape);
@@ -126,7 +145,8 @@ int32_t bnr_host_edge_index(int32_t V, int32_t l, int32_t k)
 static int alloc_trace(bnr_chain *c, int tot, double **out)
 {
     void *p = nullptr;
-    size_t bytes = (size_t)tot * c->d.rowlen * sizeof(double);
+    // + one hidden row behind the table (0-based index tot): scratch target of the purge ring with purge_burn == 1 (enqueue_run)
+    size_t bytes = (size_t)(tot + 1) * c->d.rowlen * sizeof(double);
     HIPCHK(hipMalloc(&p, bytes));
     HIPCHK(hipMemset(p, 0, bytes));
     *out = (double *)p;
@@ -145,24 +165,14 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     // static arrays, k_backproj / k_solve_a4 keep an n-vector; 160 KiB per workgroup on gfx950
     if ((size_t)R * V > 15360) return fail(BNR_ERR_BAD_ARG, "R*V must not exceed 15360 (u is staged in LDS by the scalar tail kernel)");
     if (n > 14000) return fail(BNR_ERR_BAD_ARG, "n must not exceed 14000 (n-vectors are staged in LDS)");
-    {
-        static bool lds_attr_set = false;                 // dynamic LDS beyond 64 KiB needs the attribute (once per process)
-        if (!lds_attr_set) {
-            const int big = 124 * 1024;
-            hipFuncSetAttribute((const void *)&k_tail<bnr_one>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            hipFuncSetAttribute((const void *)&k_tail<bnr_many>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            hipFuncSetAttribute((const void *)&k_backproj<bnr_one>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            hipFuncSetAttribute((const void *)&k_backproj<bnr_many>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            hipFuncSetAttribute((const void *)&k_solve_a4<bnr_one>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            hipFuncSetAttribute((const void *)&k_solve_a4<bnr_many>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipGetLastError();
-            lds_attr_set = true;
-        }
-    }
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(BNR_ERR_BAD_ARG, "no such device");
     HIPCHK(hipSetDevice(device));
+    {
+        int rc0 = ensure_lds_attributes(device);
+        if (rc0) return rc0;
+    }
     bnr_chain *c = new bnr_chain();
     c->device = device;
     bnr_dev &d = c->d;
@@ -329,6 +339,8 @@ static void drop_graph(bnr_exec &x)
 {
     if (x.gexec) { hipGraphExecDestroy(x.gexec); x.gexec = nullptr; }
     if (x.graph) { hipGraphDestroy(x.graph); x.graph = nullptr; }
+    if (x.gexec1) { hipGraphExecDestroy(x.gexec1); x.gexec1 = nullptr; }
+    if (x.graph1) { hipGraphDestroy(x.graph1); x.graph1 = nullptr; }
 }
 static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape)
 {
@@ -431,7 +443,13 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
     const int ntl = d.ntile * (d.ntile + 1) / 2;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
-        while (x.ev.size() < (size_t)(2 * (s + 1))) { hipEvent_t e; hipEventCreate(&e); x.ev.push_back(e); }
+        while (timed && x.ev.size() < (size_t)(2 * (s + 1))) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) timed = false;       // no event: the launch goes ahead untimed (n_gram shows it)
+            else x.ev.push_back(e);
+        }
+    }
+    if (timed) {
         e0 = x.ev[2 * s]; e1 = x.ev[2 * s + 1];
         hipEventRecord(e0, st);
     }
@@ -484,7 +502,11 @@ static void launch_tail(bnr_exec &x, int s, int mask, int xg_src)
 { BNR_LAUNCH(k_tail, dim3(1, 1, x.nb), dim3(1024), (size_t)x.shape->R * x.shape->V * sizeof(double), x.stream, x, s, mask, xg_src); }
 static hipEvent_t next_event(bnr_exec &x)
 {
-    if (x.fj_next >= x.fj.size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); x.fj.push_back(e); }
+    if (x.fj_next >= x.fj.size()) {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);       // a failure surfaces as the launch error of the record/wait below
+        x.fj.push_back(e);
+    }
     return x.fj[x.fj_next++];
 }
 
@@ -526,10 +548,33 @@ static int collect_gram_times(bnr_exec &x, int nsweeps)
 {
     if (!x.profiling) return BNR_OK;
     HIPCHK(hipStreamSynchronize(x.stream));
-    for (int s = 0; s < nsweeps; ++s) {
+    for (int s = 0; s < nsweeps && (size_t)(2 * s + 1) < x.ev.size(); ++s) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, x.ev[2 * s], x.ev[2 * s + 1]) == hipSuccess) { x.t_gram_acc += ms; x.n_gram += 1; }
     }
+    return BNR_OK;
+}
+
+// Capture K sweeps (+ the plan-base advance) into a graph and instantiate it.  The kernels find their plan entry through
+// pbase at run time, so a captured graph serves every later batch.
+static int capture_sweeps(bnr_exec &x, int K, hipGraph_t *graph, hipGraphExec_t *gexec)
+{
+    x.fj_next = 0;
+    HIPCHK(hipStreamBeginCapture(x.stream, hipStreamCaptureModeThreadLocal));   // other host threads may drive other handles meanwhile
+    for (int s = 0; s < K; ++s) launch_sweep(x, s, true);
+    hipLaunchKernelGGL(k_advance, dim3(x.nb), dim3(1), 0, x.stream, (const bnr_dev *)x.cds, K);
+    HIPCHK(hipStreamEndCapture(x.stream, graph));
+    HIPCHK(hipGraphInstantiate(gexec, *graph, nullptr, nullptr, 0));
+    (void)hipGraphUpload(*gexec, x.stream);                                     // best effort: the first replay finds it resident
+    (void)hipGetLastError();
+    return BNR_OK;
+}
+// Both graphs a run replays (graph_k sweeps; one sweep for the remainder): built here, outside anybody's timed region.
+static int exec_prepare(bnr_exec &x)
+{
+    if (!x.use_graph || x.profiling || x.graph_k <= 0) return BNR_OK;
+    if (!x.gexec && x.graph_k > 1) { int rc = capture_sweeps(x, x.graph_k, &x.graph, &x.gexec); if (rc) return rc; }
+    if (!x.gexec1) { int rc = capture_sweeps(x, 1, &x.graph1, &x.gexec1); if (rc) return rc; }
     return BNR_OK;
 }
 
@@ -537,25 +582,20 @@ static int launch_range(bnr_exec &x, int count)
 {
     int done = 0;
     if (x.use_graph && !x.profiling && x.graph_k > 0) {     // profiling records HIP events around k_gram: eager launches
+        int rc = exec_prepare(x);
+        if (rc) return rc;
         const int K = x.graph_k;
-        while (count - done >= K) {
-            if (!x.gexec) {
-                x.fj_next = 0;
-                HIPCHK(hipStreamBeginCapture(x.stream, hipStreamCaptureModeThreadLocal));   // other host threads may drive other handles meanwhile
-                for (int s = 0; s < K; ++s) launch_sweep(x, s, true);
-                hipLaunchKernelGGL(k_advance, dim3(x.nb), dim3(1), 0, x.stream, (const bnr_dev *)x.cds, K);
-                HIPCHK(hipStreamEndCapture(x.stream, &x.graph));
-                HIPCHK(hipGraphInstantiate(&x.gexec, x.graph, nullptr, nullptr, 0));
-            }
-            HIPCHK(hipGraphLaunch(x.gexec, x.stream));
-            done += K;
-        }
+        while (K > 1 && count - done >= K) { HIPCHK(hipGraphLaunch(x.gexec, x.stream)); done += K; }
+        while (done < count) { HIPCHK(hipGraphLaunch(x.gexec1, x.stream)); done += 1; }
+        x.n_replayed += count;
+        return BNR_OK;
     }
     const int r = count - done;
     x.fj_next = 0;
     for (int s = 0; s < r; ++s) launch_sweep(x, s, true);
     if (r > 0) {
         hipLaunchKernelGGL(k_advance, dim3(x.nb), dim3(1), 0, x.stream, (const bnr_dev *)x.cds, r);
+        x.n_eager += r;
         int rc = collect_gram_times(x, r);
         if (rc) return rc;
     }
@@ -620,8 +660,22 @@ static int enqueue_run(bnr_chain *c, int first_index, int nburn, int total, int 
     if (rc) return rc;
     c->plan_pin[0] = bnr_plan_entry{0u, 0, 0, 2};      // placeholder: the tail issued at the head of the first sweep is a no-op
     int j = first_index, prev = first_index - 2, s = 1, maxrow = 0;
+    // purge_burn == 1: the ring is rows {1, 2}; the reference writes row 2, copies it to row 1 and reads it back from there
+    // (gibbs.jl:857-860) -- a sweep here would read and write the same row.  Ping-pong instead between row 2 and the hidden
+    // scratch row behind the table, without copies, phased so that the LAST wrapping iteration L lands in the scratch row; its
+    // tail copies that state to rows 1 and 2 (what the reference's table holds at that point) and the next sweep reads the
+    // scratch row while it writes row 2.
+    const bool ring1 = purge_burn == 1 && first_index == 2 && nburn > 2;
+    const int L = ring1 ? std::min(nburn - 1, total) : 0, scratch = c->d.tot;
     for (int i = first_index; i <= total; ++i, ++s) {
         c->iter += 1;
+        if (ring1 && i <= L) {
+            const int T = ((L - i) % 2 == 0) ? scratch : 1;
+            c->plan_pin[s] = bnr_plan_entry{(uint32_t)c->iter, T, prev, i == L ? (1 | 4) : 0};
+            prev = T;
+            maxrow = std::max(maxrow, 2);
+            continue;                                                             // j stays 2 (j = 1; j = j + 1)
+        }
         bnr_plan_entry e{(uint32_t)c->iter, j - 1, prev, 0};
         maxrow = std::max(maxrow, j);
         prev = j - 1;
@@ -643,9 +697,9 @@ static int enqueue_run(bnr_chain *c, int first_index, int nburn, int total, int 
 static int run_exec(bnr_exec &x, int first_index, int count, int prog_freq, bnr_progress_cb cb, void *user)
 {
     int rc;
-    x.t_gram_acc = 0; x.n_gram = 0;
+    x.t_gram_acc = 0; x.n_gram = 0; x.n_replayed = 0; x.n_eager = 0;
     hipEvent_t r0 = nullptr, r1 = nullptr;
-    if (x.profiling) { hipEventCreate(&r0); hipEventCreate(&r1); hipEventRecord(r0, x.stream); }
+    if (x.profiling) { HIPCHK(hipEventCreate(&r0)); HIPCHK(hipEventCreate(&r1)); hipEventRecord(r0, x.stream); }
     if (cb && prog_freq > 0) {
         int s = 0;
         while (s < count) {
@@ -777,8 +831,29 @@ static int exec_last_timing(bnr_exec &x, int which, double *avg_us, int64_t *lau
 {
     if (which == 0) { *avg_us = x.t_iter_us; if (launches) *launches = x.n_iter; }
     else if (which == 1) { *avg_us = x.t_gram_us; if (launches) *launches = x.n_gram; }
-    else return fail(BNR_ERR_BAD_ARG, "which must be 0 or 1");
+    else if (which == 2) { *avg_us = (double)x.n_eager; if (launches) *launches = x.n_replayed; }   // how the last run call was issued
+    else return fail(BNR_ERR_BAD_ARG, "which must be 0, 1 or 2");
     return BNR_OK;
+}
+int bnr_group_prepare(bnr_group *g)
+{
+    if (!g) return fail(BNR_ERR_BAD_ARG, "NULL group");
+    if (g->m.empty()) return fail(BNR_ERR_BAD_ARG, "the group was dissolved (one of its chains was destroyed)");
+    HIPCHK(hipSetDevice(g->x.device));
+    int rc = exec_prepare(g->x);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g->x.stream));
+    return check_launch("prepare");
+}
+int bnr_chain_prepare(bnr_chain *c)
+{
+    if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
+    if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = exec_prepare(c->x);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->x.stream));
+    return check_launch("prepare");
 }
 int bnr_group_set_option(bnr_group *g, const char *name, int64_t value)
 {
@@ -1047,7 +1122,7 @@ int bnr_chain_resize(bnr_chain *c, int32_t new_tot)
     double *old = d.trace, *nt = nullptr;
     int rc = alloc_trace(c, new_tot, &nt);
     if (rc) return rc;
-    size_t keep = (size_t)std::min(new_tot, d.tot) * d.rowlen * sizeof(double);
+    size_t keep = (size_t)std::min(new_tot, d.tot) * d.rowlen * sizeof(double);   // the hidden scratch row holds nothing between calls
     HIPCHK(hipMemcpy(nt, old, keep, hipMemcpyDeviceToDevice));
     hipFree(old);
     d.trace = nt; d.tot = new_tot;
@@ -1253,7 +1328,7 @@ int bnr_chain_debug_time_gram(bnr_chain *c, int32_t reps, double *avg_us)
     int rc = upload_plan(c, 1);
     if (rc) return rc;
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     for (int w = 0; w < 3; ++w) launch_gram_only(c);
     hipEventRecord(e0, c->x.stream);
     for (int r = 0; r < reps; ++r) launch_gram_only(c);

@@ -27,7 +27,7 @@
 #define BNR_NB 32            // Cholesky block size
 #define BNR_GT 64            // Gram workgroup tile
 
-struct bnr_plan_entry { uint32_t it; int32_t row; int32_t prev; int32_t wrap; };   // rows 0-based
+struct bnr_plan_entry { uint32_t it; int32_t row; int32_t prev; int32_t wrap; };   // rows 0-based; wrap: 1 copy the row to row 0 (purge ring), 2 placeholder, 4 also to row 1
 
 struct bnr_dev {
     // sizes
@@ -1426,7 +1426,11 @@ __global__ __launch_bounds__(1024) void k_tail(const SRC chain_src, int s, int m
     if ((mask & 128) && (P.wrap & 1)) {
         __syncthreads();
         double *dst = cd.trace;
-        for (int i = tid; i < cd.rowlen; i += blockDim.x) dst[i] = row[i];
+        if (row != dst) for (int i = tid; i < cd.rowlen; i += blockDim.x) dst[i] = row[i];
+        if (P.wrap & 4) {                        // purge_burn == 1: the state sits in the hidden scratch row, rows 1 AND 2 get it
+            double *dst2 = cd.trace + cd.rowlen;
+            for (int i = tid; i < cd.rowlen; i += blockDim.x) dst2[i] = row[i];
+        }
     }
     BNR_TSTAMP(6);
     if (cap) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);

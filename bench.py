@@ -107,10 +107,14 @@ def main():
     one_dev = os.environ.get("BNR_BENCH_ONE_DEVICE") == "1"
     if one_dev:
         local_rank = 0
-    if a.gpus > 1 or world > 1:
+    # BNR_BENCH_FORCE_DIST=1: take the torch.distributed path also with ONE rank (RCCL communicator, barrier, all-reduce and
+    # all-gather of device tensors on a one-GPU box: the hardware rehearsal of everything in the N > 1 path but the peers)
+    if a.gpus > 1 or world > 1 or os.environ.get("BNR_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
+        if one_dev:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: never depend on what the box's hostname resolves to
         with _StdoutToStderr():
             if one_dev:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -147,6 +151,7 @@ def main():
 
     P = min(K, 200)                                  # sweeps of the HIP-event pass around k_gram (after the timed region)
 
+    runner.prepare()                                 # capture + instantiate the hipGraphs here: the timed region only replays
     if W > 0:
         run_all(2, W + 1)
     torch.cuda.synchronize()
@@ -160,6 +165,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    eager_sweeps, replayed_sweeps = runner.last_timing(2)
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -227,15 +233,22 @@ def main():
         if a.config == "cfg3" and C in (1, 8) and os.path.exists(pmc_file):
             traffic = json.load(open(pmc_file))["one" if C == 1 else "group8"].get("traffic_bytes_per_launch")
         achieved = flops_gram / (gram_us * 1e-6) / 1e12 if gram_us > 0 else 0.0
+        # whole-sweep roofline: F_iter = n^2 q + n^3/3 + 8 n q flops per chain-iteration, r = iterations/s per GPU
+        f_iter = float(n) * n * q + float(n) ** 3 / 3.0 + 8.0 * n * q
+        sweep_tflops = f_iter * (C * K / dt) / 1e12
         out = {
             "metric": "Gibbs iterations/sec (all chains)", "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic n=%d V=%d (q=%d) R=%d, %d chain(s) per GPU, %d chains total" % (n, V, q, R, C, total_chains),
+            "config": {"workload": "synthetic n=%d V=%d (q=%d) R=%d, %d chain(s) per GPU, %d chains total" % (n, V, q, R, C, total_chains)
+                                   + ("" if world == 1 else " (weak scaling: every GPU runs the %d chains of BASELINE configs[2] as one lockstep group; configs[2]'s "
+                                      "literal layout, ONE chain per GPU = %d chains on %d GPUs, is the single_chain record of this line)" % (C, world, world)),
                        "chains_per_gpu": C, "seed": a.seed},
+            "timed_region": {"sweeps_replayed_from_graphs": int(replayed_sweeps), "sweeps_launched_eagerly": int(eager_sweeps)},
             "roofline": {"bound": "mfma", "kernel": "k_gram (X diag(S) X', v_mfma_f64_16x16x4_f64)", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": "profiles/round1_gram_pmc_kg2.json (FETCH_SIZE x2 + WRITE_SIZE of a launch of this shape, separate --pmc passes, tools/pmc_gram_group.sh)",
+                         "sweep_frac": sweep_tflops / FP64_MFMA_PEAK_TFLOPS, "sweep_achieved": sweep_tflops, "sweep_flops_per_chain_iteration": f_iter,
                          "flops_per_launch": flops_gram, "avg_launch_us": gram_us, "launches_timed": gram_n,
                          "avg_launch_us_two_branch_schedule": gram_us_pipe,
                          "peak_measured_microbench": 70.0},

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BNR_ABI_VERSION 2   /* 2: + bnr_chain_create_like, bnr_group_*, bnr_chain_summary (additive) */
+#define BNR_ABI_VERSION 3   /* 2: + bnr_chain_create_like, bnr_group_*, bnr_chain_summary; 3: + bnr_*_prepare (additive) */
 
 enum {
     BNR_OK = 0,
@@ -78,6 +78,10 @@ int bnr_chain_run(bnr_chain *chain, int32_t first_index, int32_t nburn, int32_t 
  * that share one GPU overlap (the reference runs chains concurrently under pmap, gibbs.jl:946). */
 int bnr_chain_run_async(bnr_chain *chain, int32_t first_index, int32_t nburn, int32_t total, int32_t purge_burn);
 int bnr_chain_sync(bnr_chain *chain, int32_t *next_row);
+/* Optional: build everything the run loop replays (the captured hipGraphs of graph_k sweeps and of one sweep) now, so that the
+ * first bnr_chain_run / bnr_group_run call is already steady state.  run! has no counterpart (gibbs.jl:849-864 just loops);
+ * calling it is never required -- the first run call does the same lazily -- and never changes results. */
+int bnr_chain_prepare(bnr_chain *chain);
 
 /* Lockstep group: the chains one `pmap` call of generate_samples! hands to the workers (gibbs.jl:946-948, 989-1000)
  * when several of them live on ONE GPU.  All members (equal n, V, R and table length, same device) advance together:
@@ -93,6 +97,7 @@ int bnr_group_run(bnr_group *group, int32_t first_index, int32_t nburn, int32_t 
                   int32_t prog_freq, bnr_progress_cb cb, void *user, int32_t *next_row);
 /* options "graph", "graph_k", "overlap", "profiling" as for bnr_chain_set_option / bnr_chain_set_profiling; timings as
  * bnr_chain_last_timing (which = 1: one k_gram launch covers all members) */
+int bnr_group_prepare(bnr_group *group);   /* as bnr_chain_prepare */
 int bnr_group_set_option(bnr_group *group, const char *name, int64_t value);
 int bnr_group_last_timing(bnr_group *group, int32_t which, double *avg_us, int64_t *launches);
 
@@ -167,7 +172,9 @@ int bnr_rhat_from_stats(const double *stats, int32_t nchains, int32_t nparams, i
 int bnr_chain_counters(bnr_chain *chain, int64_t out[8]);
 
 /* kernel timing: average device time in microseconds of the kernels of the last bnr_chain_run call, measured
- * with HIP events on the chain's own stream.  which: 0 = whole iteration, 1 = Gram kernel (X diag(S) X'). */
+ * with HIP events on the chain's own stream.  which: 0 = whole iteration, 1 = Gram kernel (X diag(S) X');
+ * which = 2 reports how the last run call was issued: *launches = sweeps replayed from captured graphs, *avg_us = sweeps
+ * launched eagerly (a steady-state run is all replay). */
 int bnr_chain_set_profiling(bnr_chain *chain, int32_t enable);
 int bnr_chain_last_timing(bnr_chain *chain, int32_t which, double *avg_us, int64_t *launches);
 

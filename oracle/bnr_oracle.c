@@ -904,6 +904,8 @@ int orc_run(orc_t *o, int first_index, int nburn, int total, int purge_burn)
 {
     int j = first_index;
     for (int i = first_index; i <= total; ++i) {
+        if (j > o->tot) return -9;                 /* Julia: BoundsError on state.X[j,...] (e.g. purge_burn = 1 with the
+                                                      nsamp + purge_burn rows initialize_and_run! allocates, gibbs.jl:827-830) */
         o->iter += 1;
         orc_gibbs_sample(o, j - 1, (uint32_t)o->iter);
         if (o->status) return -o->status;

@@ -150,6 +150,139 @@ def test_purge_ring_and_continuation(gpu, test1):
         ch.close()
 
 
+@pytest.mark.parametrize("nburn,nsamp,stop", [(7, 5, None), (8, 4, None), (3, 3, None), (9, 4, 6), (2, 3, None)])
+def test_smallest_purge_ring(gpu, test1, nburn, nsamp, stop):
+    """purge_burn = 1, the smallest ring run! accepts (gibbs.jl:857-860: write row 2, copy it to row 1, read it back from row 1):
+    the device ping-pongs between row 2 and a hidden scratch row instead of copying; the table must equal the oracle's (which
+    copies like the reference) row for row -- odd and even burn lengths, a run that stops inside the burn-in (rows 1 and 2 then
+    both hold the last state, as after copy_table!) and continues in a second call, alone and as a member of a lockstep group.
+    With purge_burn = 1 iteration nburn lands in row 2 (not in row purge_burn as for every larger ring), so the samples need
+    nsamp + 2 rows: on the nsamp + purge_burn rows initialize_and_run! allocates (gibbs.jl:827-830) the reference stops with a
+    BoundsError at the last sample -- here the run is refused up front; the test table therefore has nsamp + 2 rows."""
+    X, y = test1
+    total = nburn + nsamp
+    rows = nsamp + 2
+    if nburn > 2:
+        short = bnr_amd.Chain(X, y, 5, nsamp + 1, 91, 1)
+        short.init_prior()
+        with pytest.raises(bnr_amd.BnrError, match="past the table"):
+            short.run(2, nburn, total, purge_burn=1)
+        short.close()
+        os_ = bo.Oracle(X, y, 5, nsamp + 1, 91, pdf_mode=1)
+        os_.init_prior()
+        with pytest.raises(RuntimeError):
+            os_.run(2, nburn, total, purge_burn=1)
+    o = bo.Oracle(X, y, 5, rows, 91, pdf_mode=1)
+    o.init_prior()
+    ch = bnr_amd.Chain(X, y, 5, rows, 91, 1)
+    mates = [bnr_amd.Chain.like(ch, 91, c, rows) for c in (2, 3)]
+    for c in [ch] + mates:
+        c.init_prior()
+    grp = bnr_amd.Group([mates[0], ch, mates[1]])
+    solo = bnr_amd.Chain.like(ch, 91, 1, rows)
+    solo.init_prior()
+    if stop is None:
+        nxt = o.run(2, nburn, total, purge_burn=1)
+        assert solo.run(2, nburn, total, purge_burn=1) == nxt == grp.run(2, nburn, total, purge_burn=1)
+    else:
+        nxt = o.run(2, nburn, stop, purge_burn=1)
+        assert solo.run(2, nburn, stop, purge_burn=1) == nxt == 2 == grp.run(2, nburn, stop, purge_burn=1)
+        assert_tables_close(solo.fetch(1, 2), o.t, rows_ref=slice(0, 2), what="stopped inside the burn-in")
+        # the reference would continue with run!(..., first_index = 2, ...) on the same table: i restarts at 2
+        rest = nburn - stop + 2
+        nxt = o.run(2, rest, rest + nsamp, purge_burn=1)
+        assert solo.run(2, rest, rest + nsamp, purge_burn=1) == nxt == grp.run(2, rest, rest + nsamp, purge_burn=1)
+    assert nxt == nsamp + 3
+    last = nxt - 1                                      # rows beyond the last written one were never touched
+    a, b = solo.fetch(1, last), ch.fetch(1, last)
+    assert_tables_close(a, o.t, rows_ref=slice(0, last), what="purge_burn=1 vs oracle")
+    for k in bo.COLUMNS:
+        assert np.array_equal(a[k], b[k]), ("group member vs chain alone", k)
+    grp.close()
+    for c in [ch, solo] + mates:
+        c.close()
+
+
+def _first_rows_match_oracle(X, y, R, seed, rows, members, what):
+    """`members` chains of one fit as ONE lockstep group (a single chain when members == 1) for `rows` rows; chain 1 (and one more
+    member) against the oracle on identical variates: discrete columns equal, everything else within RTOL."""
+    chains = [bnr_amd.Chain(X, y, R, rows, seed, 1)]
+    chains += [bnr_amd.Chain.like(chains[0], seed, c, rows) for c in range(2, members + 1)]
+    for c in chains:
+        c.init_prior()
+    grp = bnr_amd.Group(chains) if members > 1 else None
+    (grp or chains[0]).run(2, rows, rows)
+    for cid in sorted({1, members}):
+        o = bo.Oracle(X, y, R, rows, seed, chain=cid, pdf_mode=1)
+        o.init_prior()
+        o.run(2, rows, rows)
+        got = chains[cid - 1].fetch()
+        assert_tables_close(got, o.t, what="%s chain %d" % (what, cid))
+        assert chains[cid - 1].counters()["chol_fail"] == 0
+        _legal_state(got)
+    if grp:
+        grp.close()
+    for c in chains:
+        c.close()
+
+
+def _legal_state(A):
+    assert set(np.unique(A["xi"])) <= {0.0, 1.0} and set(np.unique(A["lam"])) <= {0.0, 1.0, -1.0}
+    assert np.all(A["S"] > 0) and np.all(A["tau2"] > 0) and np.all(A["theta"] > 0)
+    assert np.allclose(A["pi"].sum(axis=2), 1.0)
+    for i in range(A["M"].shape[0]):
+        M = A["M"][i]
+        assert np.allclose(M, M.T, rtol=1e-10) and np.all(np.linalg.eigvalsh(M) > 0)
+
+
+def test_config3_as_benchmarked_matches_oracle(gpu):
+    """BASELINE.json configs[2] exactly as bench.py runs it: n=500, V=100 (q=5050), R=7, the 8 chains as ONE lockstep group
+    (gibbs_sample!, gibbs.jl:663-677): five rows of chains 1 and 8 against the oracle."""
+    X, y, _ = bnr_amd.make_synthetic(500, 100, 7, seed=20240501)
+    _first_rows_match_oracle(X, y, 7, 20240501, 5, 8, "cfg3 group of 8")
+
+
+def test_config4_matches_oracle(gpu):
+    """BASELINE.json configs[3]: n=2000, V=200 (q=20100), R=7 -- 63 factorization panels, the blocked trailing update, ksplit for
+    long K: the first rows of a chain alone and of a lockstep pair against the oracle (OpenMP Gram on the host cores)."""
+    X, y, _ = bnr_amd.make_synthetic(2000, 200, 7, seed=20240501)
+    _first_rows_match_oracle(X, y, 7, 20240501, 3, 1, "cfg4 alone")
+    _first_rows_match_oracle(X, y, 7, 20240501, 3, 2, "cfg4 pair")
+
+
+def test_config5_matches_oracle(gpu):
+    """BASELINE.json configs[4]: n=500, V=300 (q=45150), R=10 -- the large-q regime (u staged in 24 KB of LDS, 1411 back-projection
+    blocks, 300 node workgroups): first rows alone and as a lockstep group of 3 against the oracle."""
+    X, y, _ = bnr_amd.make_synthetic(500, 300, 10, seed=20240501)
+    _first_rows_match_oracle(X, y, 10, 20240501, 4, 1, "cfg5 alone")
+    _first_rows_match_oracle(X, y, 10, 20240501, 3, 3, "cfg5 group of 3")
+
+
+def test_config_sizes_determinism_and_split_runs(gpu):
+    """Size-independent properties at configs[3] and configs[4] (the oracle is too slow for long runs there): two runs of one seed
+    are bitwise equal; a run split in two calls (the second call re-derives the carried sums with an explicit X*gamma pass)
+    equals the single-call run to 1e-7; every state is legal (discrete values, S > 0, pi rows sum to one, M SPD)."""
+    for (n, V, R, tot) in ((2000, 200, 7, 12), (500, 300, 10, 16)):
+        X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=20240501)
+        a = bnr_amd.Chain(X, y, R, tot, 5, 1)
+        b = bnr_amd.Chain.like(a, 5, 1, tot)
+        c = bnr_amd.Chain.like(a, 5, 1, tot)
+        for ch in (a, b, c):
+            ch.init_prior()
+        a.run(2, tot, tot)
+        b.run(2, tot, tot // 2)
+        b.run(tot // 2 + 1, tot, tot)
+        c.run(2, tot, tot)
+        A, B, Cc = a.fetch(), b.fetch(), c.fetch()
+        for k in bo.COLUMNS:
+            assert np.array_equal(A[k], Cc[k]), (n, V, k)
+            assert np.allclose(A[k], B[k], rtol=1e-7, atol=1e-10), (n, V, k)
+        _legal_state(A)
+        assert a.counters()["chol_fail"] == 0
+        for ch in (a, b, c):
+            ch.close()
+
+
 def test_table_io_move_resize(gpu):
     X, y, _ = bnr_amd.make_synthetic(30, 6, 3, seed=2)
     ch = bnr_amd.Chain(X, y, 3, 10, 5, 1)
@@ -524,34 +657,6 @@ def test_random_shapes_and_hyperparameters_match_oracle(gpu):
             c.close()
 
 
-def test_bench_multi_rank_path_rehearsal(gpu):
-    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed with two ranks on
-    this one GPU (BNR_BENCH_ONE_DEVICE=1: both ranks use device 0, exchanges over gloo instead of RCCL): rank 0 prints ONE
-    JSON line whose value aggregates the chains of both ranks."""
-    import json
-    import socket
-    import subprocess
-    import sys
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BNR_BENCH_ONE_DEVICE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "8",
-           "--chains-per-gpu", "2", "--config", "cfg2", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["warmup"] == 8 and d["scaling"] == "weak" and d["higher_is_better"] is True
-    assert "4 chains total" in d["config"]["workload"] and d["value"] > 0 and d["roofline"]["achieved"] > 0
-    assert abs(d["value"] - 4 * 40 / (d["ms_per_step"] * 40 / 1e3)) < 1e-6 * d["value"]
-    assert d["counters"]["chol_fail"] == 0 and d["single_chain"]["value"] > 0
-
-
 def test_shapes_at_the_lds_budgets(gpu):
     """u (R x V) and the n-vectors are staged in LDS by single workgroups: shapes that need more than the default 64 KiB of
     dynamic LDS run (R V = 9600: 75 KiB in k_tail; R = 32 is the latent-dimension limit), shapes beyond the 160 KiB of the
@@ -680,43 +785,3 @@ def test_progress_callback_ticks_like_run(gpu, test1):
         assert np.array_equal(A[k], B[k]), k
     a.close()
     b.close()
-
-
-_RANK_WORKER = r"""
-import os, sys
-sys.path.insert(0, {root!r})
-import numpy as np, torch.distributed as dist
-import bnr_amd
-rank = int(sys.argv[1]); os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
-dist.init_process_group("gloo", rank=rank, world_size=2)
-d = np.load({data!r}); X, y = d["X"], d["y"]
-keep = []
-res = bnr_amd.generate_samples(X, y, 5, nburn=30, nsamp=20, maxburn=30, psrf_cutoff=1.2, x_transform=False, suppress_timer=True,
-                               num_chains=3, seed=77, device=0, _keep=keep)
-assert sorted(keep[0].chains) == ([1, 3] if rank == 0 else [2])
-np.savez(sys.argv[3] + ".%d.npz" % rank, rg=res.rhatgamma, rx=res.rhatxi, has_state=np.array(res.state is not None),
-         **{{"g%d" % c: ch.fetch(31, 50)["gamma"] for c, ch in keep[0].chains.items()}})
-keep[0].close(); dist.barrier(); dist.destroy_process_group()
-"""
-
-
-def test_chains_sharded_over_two_ranks(gpu, tmp_path):
-    """Two processes (one per rank, both on this box's GPU, gloo for the exchange): chains 1..3 are sharded round-robin,
-    each rank samples its chains on the device, the per-chain Rhat messages are all-gathered and every rank finishes
-    the same Rhat, equal to rhat() over all three chains."""
-    import socket
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    script = tmp_path / "rank.py"
-    script.write_text(_RANK_WORKER.format(root=root, data=os.path.join(G, "test1_xy.npz")))
-    out = str(tmp_path / "o")
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(port), out]) for r in range(2)]
-    for p in procs:
-        assert p.wait(timeout=600) == 0
-    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
-    assert np.array_equal(r0["rg"], r1["rg"]) and np.array_equal(r0["rx"], r1["rx"])
-    assert bool(r0["has_state"]) and not bool(r1["has_state"])          # only chain 1's trace is returned (gibbs.jl:788)
-    allg = np.stack([r0["g1"][:, :, 0], r1["g2"][:, :, 0], r0["g3"][:, :, 0]], axis=2)
-    assert np.allclose(r0["rg"], bo.rhat(allg), rtol=1e-10)

@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "libbnr_hip.so does not export %s" % name
     assert declared == set(bnr_amd.EXPORTS), declared ^ set(bnr_amd.EXPORTS)
-    assert L.bnr_abi_version() == 2
+    m = re.search(r"#define BNR_ABI_VERSION (\d+)", hdr)
+    assert L.bnr_abi_version() == int(m.group(1)) >= 3
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -215,7 +216,14 @@ import numpy as np, torch, torch.distributed as dist
 import bnr_amd
 rank, world = int(sys.argv[1]), int(sys.argv[2])
 os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")        # one node: do not depend on what the hostname resolves to
 dist.init_process_group("gloo", rank=rank, world_size=world)
+# the ONE seed of a fit: drawn on rank 0, identical on every rank (gibbs.jl:739, 928); an explicit seed passes through
+import random
+s1 = bnr_amd.shared_seed(None, lambda: random.SystemRandom().randrange(1, 2**31))
+t = torch.tensor([s1], dtype=torch.int64); lst = [torch.zeros_like(t) for _ in range(world)]; dist.all_gather(lst, t)
+assert all(int(v.item()) == s1 for v in lst), lst
+assert bnr_amd.shared_seed(1234, lambda: 1 / 0) == 1234
 num_chains, width = int(sys.argv[4]), 4 * 9
 ids = bnr_amd.local_chain_ids(num_chains)
 assert ids == [c for c in range(1, num_chains + 1) if (c - 1) % world == rank], ids
