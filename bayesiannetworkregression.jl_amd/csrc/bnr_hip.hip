@@ -36,8 +36,10 @@ struct bnr_exec {
     size_t fj_next = 0;
     int overlap = 1;
     int use_graph = 1, graph_k = 8;
-    hipGraphExec_t gexec = nullptr, gexec1 = nullptr;   // graph_k sweeps / ONE sweep (the remainder of a batch is replayed too)
-    hipGraph_t graph = nullptr, graph1 = nullptr;
+    struct rung { int k; hipGraph_t graph; hipGraphExec_t gexec; };
+    std::vector<rung> ladder;                           // captured graphs of graph_k, graph_k/2, ..., 1 sweeps: any batch is replayed
+    bnr_dev *cds_pin = nullptr;                         // pinned staging of the members' descriptors
+    long long *status_dev = nullptr, *status_pin = nullptr;   // nb x 16: the members' event counters, gathered once per run call
     int64_t n_replayed = 0, n_eager = 0;                // sweeps issued by graph replay / eagerly since the last run call began
     // profiling
     int profiling = 0;
@@ -145,8 +147,9 @@ int32_t bnr_host_edge_index(int32_t V, int32_t l, int32_t k)
 static int alloc_trace(bnr_chain *c, int tot, double **out)
 {
     void *p = nullptr;
-    // + one hidden row behind the table (0-based index tot): scratch target of the purge ring with purge_burn == 1 (enqueue_run)
-    size_t bytes = (size_t)(tot + 1) * c->d.rowlen * sizeof(double);
+    // + two hidden rows behind the table (0-based tot, tot + 1): scratch target of the purge ring with purge_burn == 1
+    // (enqueue_run) and of the discarded sweeps that prime the captured graphs (prime_graphs)
+    size_t bytes = (size_t)(tot + 2) * c->d.rowlen * sizeof(double);
     HIPCHK(hipMalloc(&p, bytes));
     HIPCHK(hipMemset(p, 0, bytes));
     *out = (double *)p;
@@ -337,10 +340,8 @@ int bnr_chain_create_like(const bnr_chain *donor, uint64_t seed, int32_t chain_i
 
 static void drop_graph(bnr_exec &x)
 {
-    if (x.gexec) { hipGraphExecDestroy(x.gexec); x.gexec = nullptr; }
-    if (x.graph) { hipGraphDestroy(x.graph); x.graph = nullptr; }
-    if (x.gexec1) { hipGraphExecDestroy(x.gexec1); x.gexec1 = nullptr; }
-    if (x.graph1) { hipGraphDestroy(x.graph1); x.graph1 = nullptr; }
+    for (auto &r : x.ladder) { if (r.gexec) hipGraphExecDestroy(r.gexec); if (r.graph) hipGraphDestroy(r.graph); }
+    x.ladder.clear();
 }
 static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape)
 {
@@ -352,6 +353,9 @@ static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape)
     HIPCHK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&x.stream2, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void **)&x.cds, sizeof(bnr_dev) * nb));
+    HIPCHK(hipHostMalloc((void **)&x.cds_pin, sizeof(bnr_dev) * nb));
+    HIPCHK(hipMalloc((void **)&x.status_dev, sizeof(long long) * 16 * nb));
+    HIPCHK(hipHostMalloc((void **)&x.status_pin, sizeof(long long) * 16 * nb));
     return BNR_OK;
 }
 static void exec_free(bnr_exec &x)
@@ -364,12 +368,17 @@ static void exec_free(bnr_exec &x)
     for (hipEvent_t e : x.fj) hipEventDestroy(e);
     for (hipEvent_t e : x.ev) hipEventDestroy(e);
     if (x.cds) hipFree(x.cds);
+    if (x.cds_pin) hipHostFree(x.cds_pin);
+    if (x.status_dev) hipFree(x.status_dev);
+    if (x.status_pin) hipHostFree(x.status_pin);
     x = bnr_exec();
 }
 // the kernels read the chain's bnr_dev from device memory: refresh the copy whenever the host struct changes
 static int sync_dev(bnr_chain *c)
 {
-    HIPCHK(hipMemcpyAsync(c->x.cds, &c->d, sizeof(bnr_dev), hipMemcpyHostToDevice, c->x.stream));   // no legacy-stream calls at run time
+    HIPCHK(hipStreamSynchronize(c->x.stream));
+    c->x.cds_pin[0] = c->d;
+    HIPCHK(hipMemcpyAsync(c->x.cds, c->x.cds_pin, sizeof(bnr_dev), hipMemcpyHostToDevice, c->x.stream));   // no legacy-stream calls at run time
     HIPCHK(hipStreamSynchronize(c->x.stream));
     return BNR_OK;
 }
@@ -413,10 +422,12 @@ static int ensure_plan(bnr_chain *c, int count)
     drop_graph(c->x);                       // one chain: the struct is a by-value kernel argument baked into the captured graph
     return sync_dev(c);
 }
-static int upload_plan(bnr_chain *c, int count)
+// st: the stream the sweeps that read this plan are issued on (the chain's own, or its group's: no cross-stream hand-over)
+static int upload_plan(bnr_chain *c, int count, hipStream_t st = nullptr)
 {
-    HIPCHK(hipMemcpyAsync(c->plan_dev, c->plan_pin, sizeof(bnr_plan_entry) * count, hipMemcpyHostToDevice, c->x.stream));
-    HIPCHK(hipMemsetAsync(c->pbase_dev, 0, sizeof(int), c->x.stream));
+    if (!st) st = c->x.stream;
+    HIPCHK(hipMemcpyAsync(c->plan_dev, c->plan_pin, sizeof(bnr_plan_entry) * count, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(c->pbase_dev, 0, sizeof(int), st));
     return BNR_OK;
 }
 static int check_launch(const char *what)
@@ -569,12 +580,18 @@ static int capture_sweeps(bnr_exec &x, int K, hipGraph_t *graph, hipGraphExec_t 
     (void)hipGetLastError();
     return BNR_OK;
 }
-// Both graphs a run replays (graph_k sweeps; one sweep for the remainder): built here, outside anybody's timed region.
+// The graphs a run replays: a ladder of graph_k, graph_k/2, ..., 1 sweeps, so that a batch of any length is all replay with
+// few launches (between two graph launches the GPU idles for ~30 us: 20 sweeps = 8 + 8 + 4, not 8 + 8 + 1 + 1 + 1 + 1).
+// Built here, outside anybody's timed region.
 static int exec_prepare(bnr_exec &x)
 {
-    if (!x.use_graph || x.profiling || x.graph_k <= 0) return BNR_OK;
-    if (!x.gexec && x.graph_k > 1) { int rc = capture_sweeps(x, x.graph_k, &x.graph, &x.gexec); if (rc) return rc; }
-    if (!x.gexec1) { int rc = capture_sweeps(x, 1, &x.graph1, &x.gexec1); if (rc) return rc; }
+    if (!x.use_graph || x.profiling || x.graph_k <= 0 || !x.ladder.empty()) return BNR_OK;
+    for (int k = x.graph_k; k >= 1; k /= 2) {
+        bnr_exec::rung r{k, nullptr, nullptr};
+        int rc = capture_sweeps(x, k, &r.graph, &r.gexec);
+        x.ladder.push_back(r);                               // also on failure: drop_graph releases what exists
+        if (rc) { drop_graph(x); return rc; }
+    }
     return BNR_OK;
 }
 
@@ -584,9 +601,12 @@ static int launch_range(bnr_exec &x, int count)
     if (x.use_graph && !x.profiling && x.graph_k > 0) {     // profiling records HIP events around k_gram: eager launches
         int rc = exec_prepare(x);
         if (rc) return rc;
-        const int K = x.graph_k;
-        while (K > 1 && count - done >= K) { HIPCHK(hipGraphLaunch(x.gexec, x.stream)); done += K; }
-        while (done < count) { HIPCHK(hipGraphLaunch(x.gexec1, x.stream)); done += 1; }
+        // smallest graphs first: the GPU starts after the host has enqueued ONE short graph and works on it while the long
+        // ones are being enqueued (launching a 280-node graph costs the host a few hundred microseconds)
+        std::vector<const bnr_exec::rung *> seq;                       // greedy decomposition, largest first ...
+        for (const auto &r : x.ladder)
+            while (count - done >= r.k) { seq.push_back(&r); done += r.k; }
+        for (auto it = seq.rbegin(); it != seq.rend(); ++it) HIPCHK(hipGraphLaunch((*it)->gexec, x.stream));   // ... launched smallest first
         x.n_replayed += count;
         return BNR_OK;
     }
@@ -619,18 +639,22 @@ static int refresh_carried(bnr_chain *c, int r)
     return check_launch("refresh");
 }
 
+// status of a chain from its 16 event counters (host copy)
+static int status_of(const long long *cnt)
+{
+    if (cnt[8] > 0) return fail(BNR_ERR_HIP, "stream ordering violated: the factorization started before the Gram branch finished");
+    if (cnt[3] > 0) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "Cholesky failed after the jitter ladder (node %lld, Psi %lld, M %lld, G+I %lld)", cnt[4], cnt[5], cnt[6], cnt[7]);
+        return fail(BNR_ERR_CHOLESKY, buf);
+    }
+    return BNR_OK;
+}
 static int fetch_status(bnr_chain *c)
 {
     HIPCHK(hipMemcpyAsync(c->counters_host, c->d.counters, sizeof(long long) * 16, hipMemcpyDeviceToHost, c->x.stream));
     HIPCHK(hipStreamSynchronize(c->x.stream));
-    if (c->counters_host[8] > 0) return fail(BNR_ERR_HIP, "stream ordering violated: the factorization started before the Gram branch finished");
-    if (c->counters_host[3] > 0) {
-        char buf[160];
-        snprintf(buf, sizeof buf, "Cholesky failed after the jitter ladder (node %lld, Psi %lld, M %lld, G+I %lld)", c->counters_host[4],
-                 c->counters_host[5], c->counters_host[6], c->counters_host[7]);
-        return fail(BNR_ERR_CHOLESKY, buf);
-    }
-    return BNR_OK;
+    return status_of(c->counters_host);
 }
 
 int bnr_chain_init_prior(bnr_chain *c)
@@ -648,7 +672,7 @@ int bnr_chain_init_prior(bnr_chain *c)
 }
 
 // run! (gibbs.jl:849-864): builds the plan exactly as the reference loop walks (i, j), then enqueues the sweeps.
-static int enqueue_run(bnr_chain *c, int first_index, int nburn, int total, int purge_burn)
+static int enqueue_run(bnr_chain *c, int first_index, int nburn, int total, int purge_burn, hipStream_t st)
 {
     if (first_index < 2 || total < first_index - 1) return fail(BNR_ERR_BAD_ARG, "need first_index>=2 and total>=first_index-1");
     HIPCHK(hipSetDevice(c->device));
@@ -684,9 +708,8 @@ static int enqueue_run(bnr_chain *c, int first_index, int nburn, int total, int 
         c->plan_pin[s] = e;
     }
     if (maxrow > c->d.tot) { c->iter -= count; return fail(BNR_ERR_BAD_ARG, "run would write past the table (tot_save too small)"); }
-    rc = upload_plan(c, count + 1);
+    rc = upload_plan(c, count + 1, st);                // the caller sets the plan base of all members with ONE k_setbase launch
     if (rc) return rc;
-    hipLaunchKernelGGL(k_setbase, dim3(1), dim3(1), 0, c->x.stream, (const bnr_dev *)c->x.cds, 1);
     c->next_row = j;
     c->carried_row = -1;
     return BNR_OK;
@@ -697,6 +720,7 @@ static int enqueue_run(bnr_chain *c, int first_index, int nburn, int total, int 
 static int run_exec(bnr_exec &x, int first_index, int count, int prog_freq, bnr_progress_cb cb, void *user)
 {
     int rc;
+    hipLaunchKernelGGL(k_setbase, dim3(x.nb), dim3(1), 0, x.stream, (const bnr_dev *)x.cds, 1);
     x.t_gram_acc = 0; x.n_gram = 0; x.n_replayed = 0; x.n_eager = 0;
     hipEvent_t r0 = nullptr, r1 = nullptr;
     if (x.profiling) { HIPCHK(hipEventCreate(&r0)); HIPCHK(hipEventCreate(&r1)); hipEventRecord(r0, x.stream); }
@@ -720,6 +744,9 @@ static int run_exec(bnr_exec &x, int first_index, int count, int prog_freq, bnr_
     }
     if (count > 0) launch_tail(x, -1, 1023, 0);                        // scalar tail of the last sweep
     if (x.profiling) hipEventRecord(r1, x.stream);
+    // the members' event counters: one gather + one copy for the whole run call (read by the caller after the sync below)
+    hipLaunchKernelGGL(k_gather_counters, dim3(x.nb), dim3(16), 0, x.stream, (const bnr_dev *)x.cds, x.status_dev);
+    HIPCHK(hipMemcpyAsync(x.status_pin, x.status_dev, sizeof(long long) * 16 * x.nb, hipMemcpyDeviceToHost, x.stream));
     rc = check_launch("sweep");
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(x.stream));
@@ -738,14 +765,15 @@ int bnr_chain_run(bnr_chain *c, int32_t first_index, int32_t nburn, int32_t tota
 {
     if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
     if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending; call bnr_chain_sync first");
-    int rc = enqueue_run(c, first_index, nburn, total, purge_burn);
+    int rc = enqueue_run(c, first_index, nburn, total, purge_burn, c->x.stream);
     if (rc) return rc;
     const int count = total - first_index + 1;
+    if (count <= 0) { if (next_row) *next_row = c->next_row; return fetch_status(c); }
     rc = run_exec(c->x, first_index, count, prog_freq, cb, user);
     if (rc) return rc;
-    if (count > 0) c->carried_row = c->plan_pin[count].row;
+    c->carried_row = c->plan_pin[count].row;
     if (next_row) *next_row = c->next_row;
-    return fetch_status(c);
+    return status_of(c->x.status_pin);
 }
 
 // ------------------------------------------------------------------------------------------ lockstep groups
@@ -787,6 +815,14 @@ int bnr_group_destroy(bnr_group *g)
     return BNR_OK;
 }
 
+// the members' descriptors -> the device array the group's kernels index (pinned staging, asynchronous on the group's stream)
+static int upload_members(bnr_group *g)
+{
+    for (size_t i = 0; i < g->m.size(); ++i) g->x.cds_pin[i] = g->m[i]->d;
+    HIPCHK(hipMemcpyAsync(g->x.cds, g->x.cds_pin, sizeof(bnr_dev) * g->m.size(), hipMemcpyHostToDevice, g->x.stream));
+    return BNR_OK;
+}
+
 int bnr_group_run(bnr_group *g, int32_t first_index, int32_t nburn, int32_t total, int32_t purge_burn,
                   int32_t prog_freq, bnr_progress_cb cb, void *user, int32_t *next_row)
 {
@@ -801,18 +837,17 @@ int bnr_group_run(bnr_group *g, int32_t first_index, int32_t nburn, int32_t tota
     const int count = total - first_index + 1;
     int rc;
     for (bnr_chain *c : g->m) {
-        rc = enqueue_run(c, first_index, nburn, total, purge_burn);     // every member walks the same (i, j) schedule
+        rc = enqueue_run(c, first_index, nburn, total, purge_burn, g->x.stream);     // every member walks the same (i, j) schedule
         if (rc) return rc;
     }
-    std::vector<bnr_dev> host;
-    for (bnr_chain *c : g->m) { HIPCHK(hipStreamSynchronize(c->x.stream)); host.push_back(c->d); }
-    HIPCHK(hipMemcpyAsync(g->x.cds, host.data(), sizeof(bnr_dev) * host.size(), hipMemcpyHostToDevice, g->x.stream));
-    HIPCHK(hipStreamSynchronize(g->x.stream));
+    if (count <= 0) { if (next_row) *next_row = g->m[0]->next_row; return BNR_OK; }
+    rc = upload_members(g);
+    if (rc) return rc;
     rc = run_exec(g->x, first_index, count, prog_freq, cb, user);
     if (rc) return rc;
-    for (bnr_chain *c : g->m) {
-        if (count > 0) c->carried_row = c->plan_pin[count].row;
-        int r2 = fetch_status(c);
+    for (size_t i = 0; i < g->m.size(); ++i) {
+        g->m[i]->carried_row = g->m[i]->plan_pin[count].row;
+        int r2 = status_of(g->x.status_pin + 16 * i);
         if (r2 && !rc) rc = r2;
     }
     if (next_row) *next_row = g->m[0]->next_row;
@@ -835,15 +870,60 @@ static int exec_last_timing(bnr_exec &x, int which, double *avg_us, int64_t *lau
     else return fail(BNR_ERR_BAD_ARG, "which must be 0, 1 or 2");
     return BNR_OK;
 }
+// Replay both captured graphs ONCE on scratch rows, results discarded: the first replay of an instantiated graph pays for the
+// runtime's own setup (kernel-argument and packet buffers of ~300 nodes), and the clocks of an idle GPU take a few ms of
+// work to come up -- neither belongs into anybody's first run call.  The discarded sweeps are real sweeps from the members'
+// latest state into the two hidden rows behind each table; the table, the iteration counter and the event counters are
+// untouched, the carried sums are marked stale (the next run call re-derives them as after a load).
+// Skipped silently for a member without a state yet (init_prior / run not called).
+static int prime_graphs(bnr_exec &x, const std::vector<bnr_chain *> &members)
+{
+    if (x.ladder.empty() || x.profiling || !x.use_graph) return BNR_OK;
+    int K = 0;
+    for (const auto &r : x.ladder) K += r.k;
+    for (bnr_chain *c : members) if (c->iter < 1 || c->next_row < 2 || c->next_row - 2 >= c->d.tot || c->pending) return BNR_OK;
+    std::vector<std::vector<long long>> saved;
+    for (bnr_chain *c : members) {
+        int rc = ensure_plan(c, K + 1);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(c->x.stream));
+        saved.emplace_back(16);
+        HIPCHK(hipMemcpy(saved.back().data(), c->d.counters, sizeof(long long) * 16, hipMemcpyDeviceToHost));
+        const int src = c->next_row - 2, scr0 = c->d.tot;
+        rc = refresh_carried(c, src);                       // uses plan slot 0 itself: before the plan below is written
+        if (rc) return rc;
+        c->plan_pin[0] = bnr_plan_entry{0u, 0, 0, 2};
+        for (int s = 1; s <= K; ++s)
+            c->plan_pin[s] = bnr_plan_entry{(uint32_t)(c->iter + s), scr0 + (s & 1), s == 1 ? src : scr0 + ((s - 1) & 1), 0};
+        rc = upload_plan(c, K + 1, x.stream);
+        if (rc) return rc;
+    }
+    if (x.nb > 1) {
+        for (size_t i = 0; i < members.size(); ++i) x.cds_pin[i] = members[i]->d;
+        HIPCHK(hipMemcpyAsync(x.cds, x.cds_pin, sizeof(bnr_dev) * members.size(), hipMemcpyHostToDevice, x.stream));
+    }
+    hipLaunchKernelGGL(k_setbase, dim3(x.nb), dim3(1), 0, x.stream, (const bnr_dev *)x.cds, 1);
+    for (const auto &r : x.ladder) HIPCHK(hipGraphLaunch(r.gexec, x.stream));
+    HIPCHK(hipStreamSynchronize(x.stream));
+    for (size_t i = 0; i < members.size(); ++i) {
+        HIPCHK(hipMemcpy(members[i]->d.counters, saved[i].data(), sizeof(long long) * 16, hipMemcpyHostToDevice));
+        members[i]->carried_row = -1;
+    }
+    return check_launch("prime");
+}
+
 int bnr_group_prepare(bnr_group *g)
 {
     if (!g) return fail(BNR_ERR_BAD_ARG, "NULL group");
     if (g->m.empty()) return fail(BNR_ERR_BAD_ARG, "the group was dissolved (one of its chains was destroyed)");
     HIPCHK(hipSetDevice(g->x.device));
+    for (bnr_chain *c : g->m) if (c->d.tot != g->m[0]->d.tot) return fail(BNR_ERR_BAD_ARG, "members of a group must have tables of equal length");
     int rc = exec_prepare(g->x);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(g->x.stream));
-    return check_launch("prepare");
+    rc = check_launch("prepare");
+    if (rc) return rc;
+    return prime_graphs(g->x, g->m);
 }
 int bnr_chain_prepare(bnr_chain *c)
 {
@@ -853,7 +933,9 @@ int bnr_chain_prepare(bnr_chain *c)
     int rc = exec_prepare(c->x);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->x.stream));
-    return check_launch("prepare");
+    rc = check_launch("prepare");
+    if (rc) return rc;
+    return prime_graphs(c->x, std::vector<bnr_chain *>{c});
 }
 int bnr_group_set_option(bnr_group *g, const char *name, int64_t value)
 {
@@ -870,11 +952,12 @@ int bnr_chain_run_async(bnr_chain *c, int32_t first_index, int32_t nburn, int32_
 {
     if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
     if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is already pending");
-    int rc = enqueue_run(c, first_index, nburn, total, purge_burn);
+    int rc = enqueue_run(c, first_index, nburn, total, purge_burn, c->x.stream);
     if (rc) return rc;
     const int count = total - first_index + 1;
     int saved = c->x.profiling;
     c->x.profiling = 0;
+    hipLaunchKernelGGL(k_setbase, dim3(1), dim3(1), 0, c->x.stream, (const bnr_dev *)c->x.cds, 1);
     rc = launch_range(c->x, count);
     if (!rc && count > 0) launch_tail(c->x, -1, 1023, 0);
     c->x.profiling = saved;

@@ -1439,6 +1439,8 @@ __global__ __launch_bounds__(1024) void k_tail(const SRC chain_src, int s, int m
 // advances the plan base after a batch of sweeps (last node of the captured graph)
 __global__ void k_advance(const bnr_dev *cds, int by) { if (threadIdx.x == 0) ((int *)cds[blockIdx.x].pbase)[0] += by; }   // grid = chains
 __global__ void k_stamp(unsigned long long *dbg, int slot) { if (threadIdx.x == 0) dbg[slot] = __builtin_amdgcn_s_memrealtime(); }
+// the event counters of all members of a launch into one block (one device -> host copy per run call); grid = chains, 16 threads
+__global__ void k_gather_counters(const bnr_dev *cds, long long *out) { out[blockIdx.x * 16 + threadIdx.x] = cds[blockIdx.x].counters[threadIdx.x]; }
 __global__ void k_setbase(const bnr_dev *cds, int v) { if (threadIdx.x == 0) ((int *)cds[blockIdx.x].pbase)[0] = v; }
 
 // ===================================================================================== k_init_prior

@@ -769,6 +769,46 @@ def test_launch_modes_are_equivalent(gpu, test1):
         ch.close()
 
 
+def test_prepare_never_changes_results(gpu, test1):
+    """bnr_chain_prepare / bnr_group_prepare capture the graphs and replay them once on scratch rows: tables, iteration
+    counters and event counters of a chain alone and of a lockstep group are bitwise what they are without it -- called
+    before init_prior (nothing to replay from), after it, and between two run calls."""
+    X, y = test1
+    ref = bnr_amd.Chain(X, y, 5, 40, 31, 1)
+    ref.init_prior()
+    ref.run(2, 40, 40)
+    want = ref.fetch()
+    a = bnr_amd.Chain.like(ref, 31, 1, 40)
+    a.prepare()
+    a.init_prior()
+    a.prepare()
+    a.run(2, 40, 17)
+    a.prepare()
+    a.prepare()
+    a.run(18, 40, 40)
+    members = [bnr_amd.Chain.like(ref, 31, c, 40) for c in (2, 1, 3)]
+    for m in members:
+        m.init_prior()
+    g = bnr_amd.Group(members)
+    g.prepare()
+    g.run(2, 40, 9)
+    g.prepare()
+    g.run(10, 40, 40)
+    for got, what in ((a.fetch(), "chain"), (members[1].fetch(), "group member")):
+        for k in bo.COLUMNS:
+            assert np.allclose(got[k], want[k], rtol=1e-9, atol=1e-12), (what, k)   # split runs re-derive the carried sums
+    b = bnr_amd.Chain.like(ref, 31, 1, 40)
+    b.init_prior()
+    b.prepare()
+    b.run(2, 40, 40)
+    for k in bo.COLUMNS:
+        assert np.array_equal(b.fetch()[k], want[k]), k
+    assert a.iter == ref.iter == b.iter and a.counters() == ref.counters()
+    g.close()
+    for ch in [ref, a, b] + members:
+        ch.close()
+
+
 def test_progress_callback_ticks_like_run(gpu, test1):
     """Chain 1 ticks every prog_freq iterations (gibbs.jl:854-856); the trace does not depend on the tick frequency."""
     X, y = test1
