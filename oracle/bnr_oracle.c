@@ -674,7 +674,7 @@ void orc_update_gamma(orc_t *o, int j, uint32_t it)
     /* A = Xt * tau2D * Xt' + I :434  (Xt = X/tau) */
     {
         const int EB = 64;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) if ((double)n * n * q > 2e7)   /* small problems: a parallel region costs more than it saves (hundreds of host threads on a GPU box) */
         for (int jb = 0; jb < n; jb += 32) {
             int jend = jb + 32 < n ? jb + 32 : n;
             for (int e0 = 0; e0 < q; e0 += EB) {

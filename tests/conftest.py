@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the CPU oracle's OpenMP Gram: at most 16 threads (a GPU box shows hundreds of hardware threads; its share per GPU is 16)
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8))))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -120,6 +120,38 @@ def test_test1_csv_trace_matches_oracle_and_is_calibrated(gpu, test1):
     ch.close()
 
 
+def test_golden_run_is_a_typical_gpu_run(gpu, test1):
+    """The end-to-end pin of tests/test_oracle_golden.py::test_golden_run_is_a_typical_oracle_run repeated with GPU chains: 200
+    independent HIP runs of the golden setup (test/test1-generate-samples-test.jl:10-12: test1.csv, R=5, nburn=200, nsamp=200, one
+    chain per run, seeds 7000+i; here all advanced as ONE lockstep group) -- every window statistic of the reference's stored run
+    `res2` lies inside the central 99 % of the GPU replicate distribution (rank p >= 0.01).  Three of the runs are also compared
+    with the oracle run of the same seed (reference dense-pdf weights there, log-space weights here)."""
+    from replicates import STAT_NAMES, assert_golden_is_typical, window_stats
+    X, y = test1
+    N = 200
+    chains = [bnr_amd.Chain(X, y, 5, 400, 7000, 1)]
+    chains += [bnr_amd.Chain.like(chains[0], 7000 + i, 1, 400) for i in range(1, N)]
+    for c in chains:
+        c.init_prior()
+    grp = bnr_amd.Group(chains)
+    assert grp.run(2, 200, 400) == 401
+    reps = np.array([window_stats(c.fetch(), 200, 200) for c in chains])
+    g = np.load(os.path.join(G, "golden_res2.npz"))
+    golden = window_stats({k: g[k] for k in bo.COLUMNS}, 200, 200)
+    assert reps.shape == (N, len(STAT_NAMES)) and np.all(np.isfinite(reps))
+    p = assert_golden_is_typical(golden, reps, what="GPU:")
+    assert np.median(p) > 0.1
+    for i in (0, 57, 199):
+        o = bo.Oracle(X, y, 5, 400, 7000 + i, chain=1, pdf_mode=0)
+        o.init_prior()
+        o.run(2, 200, 400)
+        assert_tables_close(chains[i].fetch(), o.t, what="replicate %d vs oracle" % i)
+    assert all(c.counters()["chol_fail"] == 0 for c in chains[:5])
+    grp.close()
+    for c in chains:
+        c.close()
+
+
 def test_purge_ring_and_continuation(gpu, test1):
     X, y = test1
     nburn, nsamp, pb = 12, 6, 4
