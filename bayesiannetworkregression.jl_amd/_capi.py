@@ -24,6 +24,11 @@ class Hyper(C.Structure):
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int64)
+ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
+
+
+class UniqueId(C.Structure):
+    _fields_ = [("bytes", C.c_char * 128)]
 _dp = C.c_void_p
 _lib = None
 
@@ -57,6 +62,12 @@ _SIGS = {
     "bnr_chain_resize": (C.c_int, [C.c_void_p, C.c_int32]),
     "bnr_chain_rhat_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
     "bnr_chain_summary": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]),
+    "bnr_comm_unique_id": (C.c_int, [C.POINTER(UniqueId)]),
+    "bnr_comm_create_rccl": (C.c_int, [C.POINTER(UniqueId), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "bnr_comm_create_callback": (C.c_int, [C.c_int32, C.c_int32, ALLGATHER_CB, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bnr_comm_destroy": (C.c_int, [C.c_void_p]),
+    "bnr_comm_allgather": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64]),
+    "bnr_rhat": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, _dp, _dp]),
     "bnr_rhat_from_stats": (C.c_int, [_dp, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "bnr_chain_ess_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "bnr_ess_from_stats": (C.c_int, [_dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
@@ -322,6 +333,71 @@ class Group:
         us, n = C.c_double(0), C.c_int64(0)
         check(self.L.bnr_group_last_timing(self.h, which, C.byref(us), C.byref(n)))
         return us.value, n.value
+
+
+class Comm:
+    """The ranks of one fit (bnr_comm of include/bnr_hip.h): RCCL communicator owned by the library, or a host callback."""
+
+    def __init__(self, handle, rank, world, keep=None):
+        self.h, self.rank, self.world, self._keep, self.L = handle, rank, world, keep, lib()
+
+    @staticmethod
+    def unique_id():
+        uid = UniqueId()
+        check(lib().bnr_comm_unique_id(C.byref(uid)))
+        return bytes(C.string_at(C.addressof(uid), 128))
+
+    @classmethod
+    def rccl(cls, unique_id, rank, world, device):
+        """Collective: every rank calls it with rank 0's 128-byte id."""
+        uid = UniqueId()
+        C.memmove(C.addressof(uid), unique_id, 128)
+        h = C.c_void_p()
+        check(lib().bnr_comm_create_rccl(C.byref(uid), rank, world, device, C.byref(h)))
+        return cls(h, rank, world)
+
+    @classmethod
+    def callback(cls, rank, world, allgather):
+        """allgather(send: ndarray[count]) -> ndarray[world * count] in rank order (the host's own transport)."""
+        def _cb(_ctx, send, recv, count):
+            try:
+                out = np.ascontiguousarray(allgather(np.ctypeslib.as_array(send, shape=(count,)).copy()), dtype=np.float64).reshape(-1)
+                if out.size != world * count:
+                    return 2
+                C.memmove(recv, out.ctypes.data, 8 * out.size)
+                return 0
+            except Exception:                                                      # no exception may cross the ABI
+                import traceback
+                traceback.print_exc()
+                return 1
+        fn = ALLGATHER_CB(_cb)
+        h = C.c_void_p()
+        check(lib().bnr_comm_create_callback(rank, world, fn, None, C.byref(h)))
+        return cls(h, rank, world, keep=fn)
+
+    def allgather(self, send):
+        s = np.ascontiguousarray(send, dtype=np.float64).reshape(-1)
+        out = np.empty(self.world * s.size)
+        check(self.L.bnr_comm_allgather(self.h, _ptr(s), _ptr(out), s.size))
+        return out.reshape(self.world, s.size)
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.bnr_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+
+def rhat(chains, nchains_total, comm, burn, nsamp, V=None, q=None):
+    """bnr_rhat: split-Rhat of gamma and xi over ALL chains of the fit; `chains` = this rank's Chain objects in increasing
+    chain id.  Returns (rhat_gamma[q], rhat_xi[V]).  V, q are needed on a rank that holds no chain."""
+    if chains:
+        V, q = chains[0].V, chains[0].q
+    rx, rg = np.empty(V), np.empty(q)
+    arr = (C.c_void_p * max(1, len(chains)))(*[ch.h for ch in chains])
+    check(lib().bnr_rhat(arr, len(chains), nchains_total, comm.h if comm is not None else None, burn, nsamp, _ptr(rx), _ptr(rg)))
+    return rg, rx
 
 
 def ess_from_stats(stats, nsamp, max_lag):

@@ -27,7 +27,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _capi
-from ._capi import Chain, Group, ess_from_stats, new_table, rhat_from_stats
+from ._capi import Chain, Comm, Group, ess_from_stats, new_table, rhat_from_stats
 
 CITATION = ("If you use BayesianNetworkRegression.jl, please cite:\n@article{Ozminkowski2022,\n"
             "author = {Ozminkowski, S. and Sol\\'{i}s-Lemus, C.},\nyear = {2022},\n"
@@ -198,12 +198,45 @@ def shared_seed(seed, draw):
     return int(t.item())
 
 
-def allgather_stats(local_stats, num_chains):
-    """All-gather of the per-chain split-Rhat messages (4*(q+V) doubles each).  local_stats: {chain_id: array}.
-    Returns (num_chains, 4*(q+V)) in chain order on every rank.  With torch.distributed on GPUs this is one RCCL
-    all_gather of a small device tensor per rank; on CPU tests the same code runs over gloo."""
+def make_comm(device=None, force=False):
+    """The communicator of this fit for the library's own exchange (bnr_rhat): None without torch.distributed; with backend
+    nccl an RCCL communicator OWNED BY THE LIBRARY (rank 0's unique id travels through torch.distributed's object broadcast
+    -- the only thing torch is used for here); otherwise (gloo: CPU tests, one-GPU rehearsals) a callback communicator whose
+    all-gather runs over torch.distributed."""
+    d = _dist()
+    if d is None or (d.get_world_size() == 1 and not force):
+        return None
+    import torch
+    rank, world = d.get_rank(), d.get_world_size()
+    if d.get_backend() == "nccl":
+        box = [Comm.unique_id() if rank == 0 else None]
+        d.broadcast_object_list(box, src=0)
+        return Comm.rccl(box[0], rank, world, torch.cuda.current_device() if device is None else device)
+
+    def gather(send):
+        t = torch.from_numpy(send)
+        out = [torch.empty_like(t) for _ in range(world)]
+        d.all_gather(out, t)
+        return torch.stack(out).numpy()
+    return Comm.callback(rank, world, gather)
+
+
+def allgather_stats(local_stats, num_chains, comm=None):
+    """All-gather of per-chain messages of equal width (the ESS message; 4*(q+V) doubles for split-Rhat).  local_stats:
+    {chain_id: array}.  Returns (num_chains, width) in chain order on every rank.  With a library communicator (make_comm)
+    the exchange is bnr_comm_allgather (RCCL owned by the library, or the host callback); without one it falls back to
+    torch.distributed's all_gather (RCCL on GPUs, gloo on CPU tests)."""
     d = _dist()
     width = len(next(iter(local_stats.values()))) if local_stats else 0
+    if comm is not None:
+        world = comm.world
+        per_rank = (num_chains + world - 1) // world
+        width = int(comm.allgather(np.array([float(width)])).max())
+        buf = np.zeros((per_rank, width))
+        for slot, c in enumerate(sorted(local_stats)):
+            buf[slot] = local_stats[c]
+        allv = comm.allgather(buf.reshape(-1)).reshape(world, per_rank, width)
+        return np.stack([allv[(c - 1) % world, (c - 1) // world] for c in range(1, num_chains + 1)])
     if d is None:
         return np.stack([local_stats[c] for c in range(1, num_chains + 1)])
     import torch
@@ -243,6 +276,10 @@ class ChainSet:
         # panel chain of the n x n factorization is paid once per sweep of the whole group)
         self.group = Group([self.chains[c] for c in self.ids]) if len(self.chains) > 1 else None
         self.V, self.q, self.R = (next(iter(self.chains.values())).V, next(iter(self.chains.values())).q, R) if self.chains else (None, None, R)
+        if self.V is None:                                  # a rank without a chain still takes part in the exchanges
+            self.q = int(np.asarray(X_new).shape[1])
+            self.V = int((-1 + math.sqrt(1 + 8 * self.q)) / 2)
+        self.comm = make_comm(dev)
 
     def init_prior(self):
         for ch in self.chains.values():
@@ -260,18 +297,14 @@ class ChainSet:
 
     def rhat(self, first_row, nsamp):
         """split-Rhat over ALL chains of the fit for gamma (q) then xi (V) (return_psrf_VOI, gibbs.jl:771-789)."""
-        local = {c: ch.rhat_stats(first_row, nsamp) for c, ch in self.chains.items()}
-        allst = allgather_stats(local, self.num_chains)
-        r = rhat_from_stats(allst, nsamp)
-        q = (allst.shape[1] // 4) - self._V_from_width(allst.shape[1] // 4)
-        return r[:q], r[q:]
+        return _capi.rhat([self.chains[c] for c in self.ids], self.num_chains, self.comm, first_row - 1, nsamp, self.V, self.q)
 
     def ess(self, first_row, nsamp, max_lag=None):
         """Bulk effective sample size over ALL chains of the fit for gamma (q) then xi (V) -- an addition to the reference
         (split chains + Geyer's sequence, as Stan / MCMCDiagnosticTools.ess); same exchange pattern as rhat()."""
         max_lag = min(250, nsamp // 4) if max_lag is None else max_lag
         local = {c: ch.ess_stats(first_row, nsamp, max_lag) for c, ch in self.chains.items()}
-        allst = allgather_stats(local, self.num_chains)
+        allst = allgather_stats(local, self.num_chains, self.comm)
         e = ess_from_stats(allst, nsamp, max_lag)
         return e[:self.q], e[self.q:]
 
@@ -285,6 +318,9 @@ class ChainSet:
             self.group.close()
         for ch in self.chains.values():
             ch.close()
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
 
 
 # ------------------------------------------------------------------------------------------ chain driver

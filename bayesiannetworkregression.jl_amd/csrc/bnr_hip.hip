@@ -5,6 +5,8 @@
 #include "../../include/bnr_hip.h"
 #include "bnr_kernels.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -1230,6 +1232,179 @@ int bnr_chain_rhat_stats(bnr_chain *c, int32_t first_row, int32_t nsamp, double 
     hipFree(out);
     if (e != hipSuccess) return fail(BNR_ERR_HIP, std::string("rhat_stats: ") + hipGetErrorString(e));
     return check_launch("k_rhat_stats");
+}
+
+// ------------------------------------------------------------------------------------------ convergence check across ranks
+// bnr_comm: who takes part in the one exchange step of a fit -- the all-gather of the per-chain split-Rhat messages
+// (the reference returns whole state tables from its pmap workers to the master, gibbs.jl:946-957).  Two kinds:
+//   RCCL      ncclAllGather over xGMI on the library's own communicator; librccl is bound at run time with dlopen, so a
+//             single-GPU user needs no RCCL at all.  The 128-byte unique id is created on rank 0 (bnr_comm_unique_id) and
+//             carried to the other ranks by whatever already connects them (Julia Distributed, torch.distributed's store).
+//   callback  the host supplies the all-gather (tests over gloo; an MPI host; Julia remotecall).
+struct bnr_comm {
+    int rank = 0, world = 1, device = 0;
+    void *nccl = nullptr;                     // ncclComm_t
+    hipStream_t stream = nullptr;
+    bnr_allgather_fn fn = nullptr;
+    void *ctx = nullptr;
+};
+namespace {
+struct rccl_api {
+    void *dl = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, bnr_unique_id, int) = nullptr;     // ncclUniqueId is a 128-byte struct passed by value
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+rccl_api g_rccl;
+std::mutex g_rccl_mu;
+}
+static int rccl_load()
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_rccl.dl) return BNR_OK;
+    void *h = nullptr;
+    // RCCL must sit on the SAME HIP runtime this library is bound to: a process can hold two (a Python host that imports a
+    // torch wheel with its own libamdhip64 + librccl next to /opt/rocm's), and a communicator created through the other
+    // runtime fails with "unhandled cuda error".  So: look next to the libamdhip64 that hipMalloc resolves to first.
+    // RTLD_DEEPBIND: a second RCCL copy must not resolve its own internal calls into the copy loaded before it.
+    std::string tried;
+    Dl_info info;
+    if (dladdr((void *)(hipError_t (*)(void **, size_t))&hipMalloc, &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash + 1);
+            for (const char *nm : {"librccl.so.1", "librccl.so"}) {
+                h = dlopen((dir + nm).c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+                if (h) break;
+                tried += dir + nm + " ";
+            }
+        }
+    }
+    if (!h) for (const char *nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(nm, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND); if (h) break; tried += std::string(nm) + " "; }
+    if (!h) return fail(BNR_ERR_HIP, "librccl.so not found (tried " + tried + ")");
+    rccl_api a;
+    a.dl = h;
+    a.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (int (*)(void **, int, bnr_unique_id, int))dlsym(h, "ncclCommInitRank");
+    a.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    a.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+    a.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather) return fail(BNR_ERR_HIP, "librccl.so lacks an expected symbol");
+    g_rccl = a;
+    return BNR_OK;
+}
+static int rccl_fail(const char *what, int code)
+{
+    return fail(BNR_ERR_HIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(code) : "RCCL error") + " (" + std::to_string(code) + ")");
+}
+
+int bnr_comm_unique_id(bnr_unique_id *id)
+{
+    if (!id) return fail(BNR_ERR_BAD_ARG, "NULL id");
+    int rc = rccl_load();
+    if (rc) return rc;
+    int e = g_rccl.GetUniqueId(id);
+    return e ? rccl_fail("ncclGetUniqueId", e) : BNR_OK;
+}
+int bnr_comm_create_rccl(const bnr_unique_id *id, int32_t rank, int32_t world, int32_t device, bnr_comm **out)
+{
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return fail(BNR_ERR_BAD_ARG, "bad communicator arguments");
+    int rc = rccl_load();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device));
+    bnr_comm *c = new bnr_comm();
+    c->rank = rank; c->world = world; c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(BNR_ERR_HIP, "hipStreamCreate failed"); }
+    int e = g_rccl.CommInitRank(&c->nccl, world, *id, rank);
+    if (e) { hipStreamDestroy(c->stream); delete c; return rccl_fail("ncclCommInitRank", e); }
+    *out = c;
+    return BNR_OK;
+}
+int bnr_comm_create_callback(int32_t rank, int32_t world, bnr_allgather_fn fn, void *ctx, bnr_comm **out)
+{
+    if (!fn || !out || world < 1 || rank < 0 || rank >= world) return fail(BNR_ERR_BAD_ARG, "bad communicator arguments");
+    bnr_comm *c = new bnr_comm();
+    c->rank = rank; c->world = world; c->fn = fn; c->ctx = ctx;
+    *out = c;
+    return BNR_OK;
+}
+int bnr_comm_destroy(bnr_comm *c)
+{
+    if (!c) return BNR_OK;
+    if (c->nccl) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); g_rccl.CommDestroy(c->nccl); }
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return BNR_OK;
+}
+// all-gather of `count` doubles per rank: send (host) -> recv (host, world * count, rank order)
+int bnr_comm_allgather(bnr_comm *c, const double *send, double *recv, int64_t count)
+{
+    if (!send || !recv || count < 0) return fail(BNR_ERR_BAD_ARG, "bad all-gather arguments");
+    if (!c || c->world == 1) { memcpy(recv, send, sizeof(double) * (size_t)count); return BNR_OK; }
+    if (c->fn) {
+        int e = c->fn(c->ctx, send, recv, count);
+        return e ? fail(BNR_ERR_HIP, "the host's all-gather callback reported " + std::to_string(e)) : BNR_OK;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    double *ds = nullptr, *dr = nullptr;
+    HIPCHK(hipMalloc((void **)&ds, sizeof(double) * (size_t)std::max<int64_t>(count, 1)));
+    if (hipMalloc((void **)&dr, sizeof(double) * (size_t)std::max<int64_t>(count, 1) * c->world) != hipSuccess) { hipFree(ds); return fail(BNR_ERR_HIP, "hipMalloc failed"); }
+    int rc = BNR_OK;
+    hipError_t he = hipMemcpyAsync(ds, send, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess) {
+        int e = g_rccl.AllGather(ds, dr, (size_t)count, 8 /* ncclFloat64 */, c->nccl, c->stream);
+        if (e) rc = rccl_fail("ncclAllGather", e);
+    }
+    if (!rc && he == hipSuccess) he = hipMemcpyAsync(recv, dr, sizeof(double) * (size_t)count * c->world, hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    hipFree(ds); hipFree(dr);
+    if (!rc && he != hipSuccess) rc = fail(BNR_ERR_HIP, std::string("all-gather copies: ") + hipGetErrorString(he));
+    return rc;
+}
+
+// rhat() over ALL chains of a fit (convergence.jl:4-65 + return_psrf_VOI, gibbs.jl:771-789): chains c = 1..nchains_total live
+// round-robin on the ranks ((c - 1) % world == rank, in increasing c: the reference's pmap order).  Every local chain reduces
+// its window on the device, the 4 (q + V)-double messages are all-gathered, every rank finishes the same Rhat.
+int bnr_rhat(bnr_chain *const *chains, int32_t nchains_local, int32_t nchains_total, bnr_comm *comm, int32_t burn, int32_t nsamp,
+             double *rhat_xi, double *rhat_gamma)
+{
+    if (nchains_total < 1 || nchains_local < 0 || (nchains_local > 0 && !chains) || !rhat_xi || !rhat_gamma) return fail(BNR_ERR_BAD_ARG, "bad argument");
+    const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
+    int expect = 0;
+    for (int c = 1; c <= nchains_total; ++c) if ((c - 1) % world == rank) ++expect;
+    if (expect != nchains_local) return fail(BNR_ERR_BAD_ARG, "this rank must hold the chains c with (c-1) % world == rank");
+    const int per_rank = (nchains_total + world - 1) / world;
+    // every rank needs q and V also when it holds no chain: they travel in front of the messages
+    int q = 0, V = 0;
+    if (nchains_local > 0) { if (!chains[0]) return fail(BNR_ERR_BAD_ARG, "NULL chain"); q = chains[0]->d.q; V = chains[0]->d.V; }
+    {
+        std::vector<double> mine{(double)q, (double)V}, all(2 * (size_t)world);
+        int rc = bnr_comm_allgather(comm, mine.data(), all.data(), 2);
+        if (rc) return rc;
+        for (int r = 0; r < world; ++r) if (all[2 * r] > 0) { q = (int)all[2 * r]; V = (int)all[2 * r + 1]; }
+    }
+    if (q <= 0 || V <= 0) return fail(BNR_ERR_BAD_ARG, "no rank holds a chain");
+    const int np = q + V;
+    const size_t width = (size_t)4 * np;
+    std::vector<double> send(width * per_rank, 0.0), recv(width * per_rank * world);
+    for (int i = 0; i < nchains_local; ++i) {
+        if (!chains[i] || chains[i]->d.q != q || chains[i]->d.V != V) return fail(BNR_ERR_BAD_ARG, "chains of one fit must have equal V");
+        int rc = bnr_chain_rhat_stats(chains[i], burn + 1, nsamp, send.data() + width * i);
+        if (rc) return rc;
+    }
+    int rc = bnr_comm_allgather(comm, send.data(), recv.data(), (int64_t)send.size());
+    if (rc) return rc;
+    std::vector<double> stats(width * nchains_total), rh(np);
+    for (int c = 1; c <= nchains_total; ++c)
+        memcpy(stats.data() + width * (c - 1), recv.data() + width * ((size_t)((c - 1) % world) * per_rank + (c - 1) / world), sizeof(double) * width);
+    rc = bnr_rhat_from_stats(stats.data(), nchains_total, np, nsamp, rh.data());
+    if (rc) return rc;
+    memcpy(rhat_gamma, rh.data(), sizeof(double) * q);
+    memcpy(rhat_xi, rh.data() + q, sizeof(double) * V);
+    return BNR_OK;
 }
 
 // Summary(results) on the device (gibbs.jl:1214-1250): posterior mean and two order statistics of every gamma_e over rows

@@ -31,41 +31,48 @@ FP64_MFMA_PEAK_TFLOPS = 78.6               # AMD MI355X FP64 matrix spec (not in
 
 
 _CPU_WORKER = r"""
-import sys, time
+import os, sys, time
 sys.path.insert(0, sys.argv[1])
 import numpy as np
 import bnr_amd
 from oracle import bnr_oracle as bo
-n, V, R, seed, chain, budget = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), float(sys.argv[7])
+n, V, R, seed, chain, budget, mode, threads = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), float(sys.argv[7]), int(sys.argv[8]), int(sys.argv[9])
+blas = bo.use_numpy_openblas(threads) if mode == 2 else None
+if mode == 2 and blas is None:
+    mode = 1
 X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=seed)
 tot = 256
-o = bo.Oracle(X, y, R, tot, seed, chain=chain, pdf_mode=0, cost_mode=1)
+o = bo.Oracle(X, y, R, tot, seed, chain=chain, pdf_mode=0, cost_mode=mode)
 o.init_prior()
 o.gibbs_sample(1, 2)                      # warm-up (page faults, thread pool)
 t0 = time.time(); done = 1
 while done < tot - 1 and (done < 3 or time.time() - t0 < budget):
     o.gibbs_sample(done + 1, done + 2); done += 1
-print(done - 1, time.time() - t0, bo.lib().orc_num_threads())
+print(done - 1, time.time() - t0, threads, mode, "|", blas or "")
 """
 
 
-def cpu_baseline(n, V, R, seed, nchains, budget_s=15.0):
-    """The CPU oracle in reference-cost mode (full 2n^2 q GEMM, LU solve, dense (V-1)-dim pdfs) on the host cores: the
-    same `nchains` chains as one OS process each (the reference's pmap workers, gibbs.jl:946), the host's hardware
-    threads divided among them (OpenMP over the Gram columns inside a chain).  Iterations/s summed over the chains."""
+def cpu_baseline(n, V, R, seed, nchains, budget_s=15.0, mode=2):
+    """The CPU oracle in reference-cost mode on the host cores: the same `nchains` chains as one OS process each (the reference's
+    pmap workers, gibbs.jl:946), the host's hardware threads divided among them; iterations/s summed over the chains.
+      mode 2: as the reference executes update_gamma! -- X/tau and Xt*tau2D copies, dense 2 n^2 q dgemm and LU solve by OpenBLAS
+              (numpy's bundled libscipy_openblas: the reference's Julia links OpenBLAS too), dense (V-1)-dim pdfs;
+      mode 1: the same operation counts with the oracle's own plain-C loops (OpenMP over the Gram columns), no BLAS."""
     import subprocess
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    per = max(1, ncpu // nchains)
-    env = dict(os.environ, OMP_NUM_THREADS=str(per))
-    procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, str(n), str(V), str(R), str(seed), str(c + 1), str(budget_s)],
+    per = max(1, min(64, ncpu // nchains))                  # numpy's OpenBLAS is built with MAX_THREADS = 64
+    env = dict(os.environ, OMP_NUM_THREADS=str(per), OPENBLAS_NUM_THREADS=str(per))
+    procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, str(n), str(V), str(R), str(seed), str(c + 1), str(budget_s), str(mode), str(per)],
                               stdout=subprocess.PIPE, env=env, text=True) for c in range(nchains)]
-    rate, its, threads = 0.0, 0, 0
+    rate, its, threads, used, blas = 0.0, 0, 0, mode, ""
     for p in procs:
-        out = p.communicate(timeout=600)[0].split()
-        its += int(out[0]); rate += int(out[0]) / float(out[1]); threads += int(out[2])
+        head, _, tail = p.communicate(timeout=600)[0].partition("|")
+        out = head.split()
+        its += int(out[0]); rate += int(out[0]) / float(out[1]); threads += int(out[2]); used = int(out[3]); blas = tail.strip()
+    how = ("Gram (dense 2n^2q dgemm) and LU solve by OpenBLAS: " + blas) if used == 2 else "plain-C loops of the oracle (OpenMP Gram, unblocked LU), no BLAS"
     return dict(value=rate, unit="Gibbs iterations/s (all chains)", cores=threads, kind="port",
                 sample="%d chains x ~%.0f s of the same n/V/R workload (%d iterations in all), one process per chain with %d "
-                       "OpenMP threads each" % (nchains, budget_s, its, per))
+                       "threads each; reference-cost mode: %s" % (nchains, budget_s, its, per, how))
 
 
 class _StdoutToStderr:
@@ -212,23 +219,36 @@ def main():
         single = {"value": world * Ks / dts, "unit": "iterations/s", "chains_per_gpu": 1, "steps": Ks, "ms_per_step": 1e3 * dts / Ks}
         solo.close()
 
-    # convergence check over all chains of the job: RCCL all-gather of the per-chain split-Rhat messages
+    # convergence check over all chains of the job (return_psrf_VOI, gibbs.jl:771-789): bnr_rhat -- device reduction per chain, ONE
+    # all-gather of the 4 (q + V)-double messages on the library's own RCCL communicator (ncclAllGather over xGMI; its unique id
+    # travels through torch.distributed), Rhat finished on every rank.  Not timed.  Should the communicator not come up, the
+    # messages go through torch.distributed's all_gather instead and the JSON line says so.
+    from bnr_amd import _capi
     nsamp = K
+    comm, exchange = None, "one process, no exchange"
+    if dist:
+        try:
+            comm = bnr_amd.make_comm(device=local_rank, force=True)
+            exchange = "bnr_rhat: ncclAllGather on the library's RCCL communicator" if dist.get_backend() == "nccl" else "bnr_rhat: host-callback communicator over gloo"
+        except bnr_amd.BnrError as e:
+            exchange = "torch.distributed all_gather (library communicator unavailable: %s)" % e
     rh = None
     if nsamp >= 4:                                               # split-Rhat needs two samples per half
-        local = {cid: ch.rhat_stats(W + 2, nsamp) for cid, ch in zip(ids, chains)}
-        if dist:
-            stats = bnr_amd.allgather_stats(local, world * C)
+        if comm is not None or not dist:
+            rg, rx = _capi.rhat(chains, world * C, comm, W + 1, nsamp)
+            rh = np.concatenate([rg, rx])
         else:
-            stats = np.stack([local[c] for c in sorted(local)])
-        rh = bnr_amd.rhat_from_stats(stats, nsamp)
+            local = {cid: ch.rhat_stats(W + 2, nsamp) for cid, ch in zip(ids, chains)}
+            rh = bnr_amd.rhat_from_stats(bnr_amd.allgather_stats(local, world * C), nsamp)
     # effective sample size of the timed window over all chains (an addition to the reference's Rhat; same exchange pattern)
     ess = None
     if nsamp >= 64:
         Lag = min(250, nsamp // 4)
         local_e = {cid: ch.ess_stats(W + 2, nsamp, Lag) for cid, ch in zip(ids, chains)}
-        stats_e = bnr_amd.allgather_stats(local_e, world * C) if dist else np.stack([local_e[c] for c in sorted(local_e)])
+        stats_e = bnr_amd.allgather_stats(local_e, world * C, comm) if dist else np.stack([local_e[c] for c in sorted(local_e)])
         ess = bnr_amd.ess_from_stats(stats_e, nsamp, Lag)
+    if comm is not None:
+        comm.close()
 
     if rank == 0:
         total_chains = world * C
@@ -261,12 +281,13 @@ def main():
             "max_rhat_gamma": None if rh is None else float(np.nanmax(rh[:q])), "max_rhat_xi": None if rh is None else float(np.nanmax(rh[q:])),
             "ess_gamma": None if ess is None else {"min": float(np.nanmin(ess[:q])), "median": float(np.nanmedian(ess[:q])),
                                                    "draws": int(nsamp * world * C), "min_per_second": float(np.nanmin(ess[:q]) / dt)},
-            "counters": counters,
+            "counters": counters, "rhat_exchange": exchange,
         }
         if single is not None:
             out["single_chain"] = single
         if not a.no_cpu_baseline and world == 1:            # the host-core baseline is taken at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(n, V, R, a.seed, C)
+            out["cpu_baseline"] = cpu_baseline(n, V, R, a.seed, C, 15.0, 2)
+            out["cpu_baseline_no_blas"] = cpu_baseline(n, V, R, a.seed, C, 6.0, 1)
         print(json.dumps(out))
     for ch in chains:
         ch.close()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BNR_ABI_VERSION 3   /* 2: + bnr_chain_create_like, bnr_group_*, bnr_chain_summary; 3: + bnr_*_prepare (additive) */
+#define BNR_ABI_VERSION 4   /* 2: + bnr_chain_create_like, bnr_group_*, bnr_chain_summary; 3: + bnr_*_prepare; 4: + bnr_comm_*, bnr_rhat (additive) */
 
 enum {
     BNR_OK = 0,
@@ -162,6 +162,28 @@ int bnr_chain_summary(bnr_chain *chain, int32_t first_row, int32_t nsamp, int32_
  *   NaN for a constant parameter.  ess[nparams]. */
 int bnr_chain_ess_stats(bnr_chain *chain, int32_t first_row, int32_t nsamp, int32_t max_lag, double *stats);
 int bnr_ess_from_stats(const double *stats, int32_t nchains, int32_t nparams, int32_t nsamp, int32_t max_lag, double *ess);
+
+/* The convergence check over ALL chains of a fit, wherever they live (return_psrf_VOI, gibbs.jl:771-789, over rhat(),
+ * convergence.jl:4-65; the reference's master receives whole state tables from its pmap workers, gibbs.jl:946-957 -- here only
+ * 4 (q + V) doubles per chain travel).  Chains c = 1..nchains_total are placed round-robin: rank r holds, in increasing c, the
+ * chains with (c - 1) % world == r.  bnr_rhat reduces every local chain's window rows burn+1 .. burn+nsamp on the device,
+ * all-gathers the messages through `comm`, and finishes the same rhat_xi[V] / rhat_gamma[q] on every rank.
+ * comm == NULL: one process holds all chains.
+ * A communicator is either RCCL (ncclAllGather over xGMI on the library's own communicator; librccl.so is bound at run time, so
+ * single-GPU use needs no RCCL) -- rank 0 calls bnr_comm_unique_id and the host carries the 128 bytes to the other ranks by
+ * whatever connects them already (Julia Distributed, torch.distributed's store, MPI), then every rank calls bnr_comm_create_rccl
+ * (a collective call) -- or a callback the host implements (an all-gather of `count` doubles per rank into recv[world * count] in
+ * rank order, returning 0; used by the gloo tests and by hosts that bring their own transport). */
+typedef struct bnr_comm bnr_comm;
+typedef struct { char bytes[128]; } bnr_unique_id;                       /* ncclUniqueId */
+typedef int (*bnr_allgather_fn)(void *ctx, const double *send, double *recv, int64_t count);
+int bnr_comm_unique_id(bnr_unique_id *id);
+int bnr_comm_create_rccl(const bnr_unique_id *id, int32_t rank, int32_t world, int32_t device, bnr_comm **out);
+int bnr_comm_create_callback(int32_t rank, int32_t world, bnr_allgather_fn fn, void *ctx, bnr_comm **out);
+int bnr_comm_destroy(bnr_comm *comm);
+int bnr_comm_allgather(bnr_comm *comm, const double *send, double *recv, int64_t count);   /* host buffers; comm NULL = copy */
+int bnr_rhat(bnr_chain *const *chains, int32_t nchains_local, int32_t nchains_total, bnr_comm *comm, int32_t burn, int32_t nsamp,
+             double *rhat_xi, double *rhat_gamma);
 
 /* second half: combine nchains messages (host arrays, chain-major) into Rhat per parameter.  Pure host code.
  * rhat: q+V doubles (gamma first, then xi).  Replaces convergence.jl:49-61. */

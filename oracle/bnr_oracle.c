@@ -646,6 +646,17 @@ void orc_update_u_xi(orc_t *o, int j, uint32_t it)
     free(mu_t); free(z); free(Lc);
 }
 
+/* Optional BLAS/LAPACK back end for the reference-cost timing mode (cost_mode = 2): Fortran-interface dgemm / dgesv with 64-bit
+ * integers (numpy's bundled OpenBLAS: scipy_dgemm_64_, scipy_dgesv_64_), handed in as plain function addresses by the Python
+ * side -- the reference's `Xt*tau2D*transpose(Xt)` is an OpenBLAS gemm and its `\` an LAPACK getrf/getrs (gibbs.jl:434). */
+typedef void (*orc_dgemm_t)(const char *, const char *, const int64_t *, const int64_t *, const int64_t *, const double *, const double *,
+                            const int64_t *, const double *, const int64_t *, const double *, double *, const int64_t *);
+typedef void (*orc_dgesv_t)(const int64_t *, const int64_t *, double *, const int64_t *, int64_t *, double *, const int64_t *, int64_t *);
+static orc_dgemm_t g_dgemm = 0;
+static orc_dgesv_t g_dgesv = 0;
+void orc_set_blas(void *dgemm, void *dgesv) { g_dgemm = (orc_dgemm_t)dgemm; g_dgesv = (orc_dgesv_t)dgesv; }
+int orc_have_blas(void) { return g_dgemm && g_dgesv; }
+
 /* ------------------------------------------------------------------ update_gamma! (gibbs.jl:420-438) */
 void orc_update_gamma(orc_t *o, int j, uint32_t it)
 {
@@ -672,6 +683,24 @@ void orc_update_gamma(orc_t *o, int j, uint32_t it)
         a3[i] += draw_normal(o->seed, it, SITE_G_Z2, (uint32_t)i, 0);               /* :430 */
     }
     /* A = Xt * tau2D * Xt' + I :434  (Xt = X/tau) */
+    if (o->cost_mode == 2 && orc_have_blas()) {
+        /* as the reference executes it: Xt = X ./ tau (a copy, :425), Xt * tau2D (Diagonal product: another n x q copy), then a
+         * dense gemm with transpose(Xt), the identity added, and a general LU solve */
+        double *Xt = (double *)malloc(sizeof(double) * (size_t)n * q), *XD = (double *)malloc(sizeof(double) * (size_t)n * q);
+        for (size_t e = 0; e < (size_t)q; ++e) {
+            const double *xc = o->X + (size_t)n * e; double *tc = Xt + (size_t)n * e, *dc = XD + (size_t)n * e, de = d[e];
+            for (int i = 0; i < n; ++i) { tc[i] = xc[i] / tau; dc[i] = tc[i] * de; }
+        }
+        const int64_t nn = n, qq = q, one = 1; const double alpha = 1.0, beta = 0.0;
+        g_dgemm("N", "T", &nn, &nn, &qq, &alpha, XD, &nn, Xt, &nn, &beta, A, &nn);
+        for (int i = 0; i < n; ++i) A[i + (size_t)n * i] += 1.0;
+        for (int i = 0; i < n; ++i) a1[i] -= a3[i];
+        int64_t *ipiv = (int64_t *)malloc(sizeof(int64_t) * n), info = 0;
+        g_dgesv(&nn, &one, A, &nn, ipiv, a1, &nn, &info);
+        if (info != 0) o->status = 3;
+        free(ipiv); free(Xt); free(XD);
+        goto solved;
+    }
     {
         const int EB = 64;
 #pragma omp parallel for schedule(dynamic, 1) if ((double)n * n * q > 2e7)   /* small problems: a parallel region costs more than it saves (hundreds of host threads on a GPU box) */
@@ -697,6 +726,7 @@ void orc_update_gamma(orc_t *o, int j, uint32_t it)
     }
     for (int i = 0; i < n; ++i) a1[i] -= a3[i];
     if (lu_solve(A, n, a1)) o->status = 3;                    /* a4 = A \ (a1 - a3) */
+solved:
     /* a5 = dg1 + tau2D * Xt' a4 :435 ; gamma = a5 + W :436 */
     for (int e = 0; e < q; ++e) {
         const double *xc = o->X + (size_t)n * e; double s = 0.0;

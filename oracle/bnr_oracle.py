@@ -55,7 +55,38 @@ def lib():
         _lib.orc_sample_gig.restype = C.c_double
         _lib.orc_sample_gig.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32]
         _lib.orc_run.restype = C.c_int
+        _lib.orc_set_blas.argtypes = [C.c_void_p, C.c_void_p]
     return _lib
+
+
+_blas = None
+
+
+def use_numpy_openblas(threads=None):
+    """Back the reference-cost timing mode (cost_mode=2) with the OpenBLAS that ships inside numpy's wheel (numpy.libs/
+    libscipy_openblas64_*.so: ILP64 Fortran symbols scipy_dgemm_64_ / scipy_dgesv_64_) -- the image has no system BLAS.
+    Returns a description string, or None when the library or a symbol is missing (cost_mode 2 then behaves like 1)."""
+    global _blas
+    import glob
+    import numpy
+    if _blas is None:
+        cand = glob.glob(os.path.join(os.path.dirname(numpy.__file__), "..", "numpy.libs", "libscipy_openblas*.so"))
+        for path in cand:
+            try:
+                B = C.CDLL(path)
+                gemm, gesv = C.cast(B.scipy_dgemm_64_, C.c_void_p), C.cast(B.scipy_dgesv_64_, C.c_void_p)
+            except (OSError, AttributeError):
+                continue
+            lib().orc_set_blas(gemm, gesv)
+            _blas = (B, os.path.basename(path))
+            break
+    if _blas is None:
+        return None
+    B, name = _blas
+    if threads is not None:
+        B.scipy_openblas_set_num_threads64_(C.c_int(int(threads)))
+    B.scipy_openblas_get_config64_.restype = C.c_char_p
+    return "%s (%s), %d threads" % (name, B.scipy_openblas_get_config64_().decode().strip(), B.scipy_openblas_get_num_threads64_())
 
 
 def table_shapes(V, R):

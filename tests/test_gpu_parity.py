@@ -801,6 +801,37 @@ def test_launch_modes_are_equivalent(gpu, test1):
         ch.close()
 
 
+def test_rhat_through_the_library_communicator(gpu, test1):
+    """bnr_rhat (return_psrf_VOI, gibbs.jl:771-789, over rhat(), convergence.jl:4-65) with every kind of communicator a one-GPU
+    box can hold: none (one process), the library's own RCCL communicator of one rank (ncclCommInitRank + ncclAllGather really
+    run), and a host-callback communicator -- all equal the oracle's rhat over the fetched traces."""
+    X, y = test1
+    chains = [bnr_amd.Chain(X, y, 5, 60, 5, 1)]
+    chains += [bnr_amd.Chain.like(chains[0], 5, c, 60) for c in (2, 3)]
+    for c in chains:
+        c.init_prior()
+    g = bnr_amd.Group(chains)
+    g.run(2, 20, 60)
+    gam = np.stack([c.fetch(21, 60)["gamma"][:, :, 0] for c in chains], axis=2)
+    xi = np.stack([c.fetch(21, 60)["xi"][:, :, 0] for c in chains], axis=2)
+    want_g, want_x = bo.rhat(gam), bo.rhat(xi)
+    from bnr_amd import _capi
+    rccl = bnr_amd.Comm.rccl(bnr_amd.Comm.unique_id(), 0, 1, 0)
+    assert np.array_equal(rccl.allgather(np.arange(7.0)), np.arange(7.0)[None, :])
+    calls = []
+    cb = bnr_amd.Comm.callback(0, 1, lambda send: calls.append(send.size) or send[None, :])
+    for comm in (None, rccl, cb):
+        rg, rx = _capi.rhat(chains, 3, comm, 20, 40)
+        assert np.allclose(rg, want_g, rtol=1e-10) and np.allclose(rx, want_x, rtol=1e-10, equal_nan=True)
+    with pytest.raises(bnr_amd.BnrError, match="must hold the chains"):
+        _capi.rhat(chains[:2], 3, None, 20, 40)
+    rccl.close()
+    cb.close()
+    g.close()
+    for c in chains:
+        c.close()
+
+
 def test_prepare_never_changes_results(gpu, test1):
     """bnr_chain_prepare / bnr_group_prepare capture the graphs and replay them once on scratch rows: tables, iteration
     counters and event counters of a chain alone and of a lockstep group are bitwise what they are without it -- called

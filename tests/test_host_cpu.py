@@ -224,6 +224,11 @@ s1 = bnr_amd.shared_seed(None, lambda: random.SystemRandom().randrange(1, 2**31)
 t = torch.tensor([s1], dtype=torch.int64); lst = [torch.zeros_like(t) for _ in range(world)]; dist.all_gather(lst, t)
 assert all(int(v.item()) == s1 for v in lst), lst
 assert bnr_amd.shared_seed(1234, lambda: 1 / 0) == 1234
+# the library's communicator with the host's transport behind it (callback seam of bnr_comm_*): gloo here, RCCL on GPUs
+comm = bnr_amd.make_comm()
+got = comm.allgather(np.arange(5.0) + 10 * rank)
+assert got.shape == (world, 5) and all(np.array_equal(got[r], np.arange(5.0) + 10 * r) for r in range(world)), got
+comm.close()
 num_chains, width = int(sys.argv[4]), 4 * 9
 ids = bnr_amd.local_chain_ids(num_chains)
 assert ids == [c for c in range(1, num_chains + 1) if (c - 1) % world == rank], ids

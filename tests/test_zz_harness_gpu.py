@@ -61,6 +61,7 @@ def test_bench_multi_rank_path_rehearsal(gpu, tmp_path):
     assert "4 chains total" in d["config"]["workload"] and d["value"] > 0 and d["roofline"]["achieved"] > 0
     assert abs(d["value"] - 4 * 40 / (d["ms_per_step"] * 40 / 1e3)) < 1e-6 * d["value"]
     assert d["counters"]["chol_fail"] == 0 and d["single_chain"]["value"] > 0
+    assert d["rhat_exchange"].startswith("bnr_rhat: host-callback"), d["rhat_exchange"]
     assert d["timed_region"]["sweeps_launched_eagerly"] == 0 and d["timed_region"]["sweeps_replayed_from_graphs"] == 40
 
 
@@ -71,6 +72,7 @@ def test_bench_one_rank_rccl_path(gpu, tmp_path):
     d = _run_bench_ranks(tmp_path, 1, ["--steps", "24", "--warmup", "3", "--chains-per-gpu", "2", "--config", "cfg2", "--no-cpu-baseline"],
                          dict(BNR_BENCH_FORCE_DIST="1"))
     assert d["n_gpus"] == 1 and d["steps"] == 24 and d["value"] > 0 and d["max_rhat_gamma"] > 0
+    assert d["rhat_exchange"].startswith("bnr_rhat: ncclAllGather"), d["rhat_exchange"]
     assert d["timed_region"]["sweeps_launched_eagerly"] == 0 and d["timed_region"]["sweeps_replayed_from_graphs"] == 24
     assert 0 < d["roofline"]["sweep_frac"] < 1 and 0 < d["roofline"]["frac"] < 1
 
