@@ -36,6 +36,8 @@ _SIGS = {
     "bnr_abi_version": (C.c_int, []),
     "bnr_last_error": (C.c_char_p, []),
     "bnr_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "bnr_device_synchronize": (C.c_int, [C.c_int32]),
+    "bnr_runtime_version": (C.c_int, [C.POINTER(C.c_int)]),
     "bnr_chain_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(Hyper), C.c_uint64, C.c_int32,
                                    C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "bnr_chain_create_like": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -137,6 +139,16 @@ def device_count():
     n = C.c_int(0)
     check(lib().bnr_device_count(C.byref(n)))
     return n.value
+
+
+def device_synchronize(device=0):
+    check(lib().bnr_device_synchronize(int(device)))
+
+
+def runtime_version():
+    v = C.c_int(0)
+    check(lib().bnr_runtime_version(C.byref(v)))
+    return v.value
 
 
 class Chain:

@@ -123,6 +123,18 @@ static int sync_dev(bnr_chain *c);
 
 int bnr_abi_version(void) { return BNR_ABI_VERSION; }
 const char *bnr_last_error(void) { return g_err.c_str(); }
+int bnr_device_synchronize(int32_t device)
+{
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    return BNR_OK;
+}
+int bnr_runtime_version(int *version)
+{
+    if (!version) return fail(BNR_ERR_BAD_ARG, "version is NULL");
+    HIPCHK(hipRuntimeGetVersion(version));
+    return BNR_OK;
+}
 int bnr_device_count(int *count)
 {
     if (!count) return fail(BNR_ERR_BAD_ARG, "count is NULL");

@@ -1226,8 +1226,8 @@ __global__ __launch_bounds__(1024) void k_tail(const SRC chain_src, int s, int m
 
     // ---- phase 1: reductions.  Psum partials (32 lanes per output, fixed order); X gamma from the PG partials
     if (mask & (1 | 16)) {
-        const int nout = 1 + 3 * R, j = tid >> 5, t = tid & 31;
-        for (int jj = j; jj < nout; jj += 32) {
+        const int nout = 1 + 3 * R, j = tid >> 5, t = tid & 31, ngrp = blockDim.x >> 5;
+        for (int jj = j; jj < nout; jj += ngrp) {
             double a0 = 0.0, a1 = 0.0;
             int b = t;
             for (; b + 32 < cd.nblk_bp; b += 64) { a0 += cd.Psum[(size_t)b * nout + jj]; a1 += cd.Psum[(size_t)(b + 32) * nout + jj]; }

@@ -101,37 +101,53 @@ def main():
     ap.add_argument("--seed", type=int, default=20240501)
     ap.add_argument("--overlap", type=int, default=1, help="0: single-stream schedule (diagnostics)")
     ap.add_argument("--graph-k", type=int, default=0, help="sweeps per captured graph (0: library default)")
+    ap.add_argument("--graph", type=int, default=1, help="0: launch every kernel eagerly (diagnostics)")
     a = ap.parse_args()
 
     import numpy as np
-    import torch
     import bnr_amd
+    # The library binds the SYSTEM's HIP runtime and RCCL (/opt/rocm, ROCm 7.2): it is loaded before torch, whose wheel carries
+    # its own libamdhip64/librccl (ROCm 7.0) -- whichever HIP runtime is loaded first serves the whole process.  torch is used
+    # below ONLY as the rendezvous of the ranks (torch.distributed over gloo/TCP on the loopback: barriers, the broadcast of the
+    # RCCL unique id); it never initialises the GPU.  Every device-side exchange runs on the library's own RCCL communicator.
+    bnr_amd.lib()
+    bnr_amd.device_count()                         # initialises that HIP runtime now (it must come up before torch's copies are loaded)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    # rehearsal of the multi-rank path on a one-GPU box: every rank uses device 0, the exchanges run over gloo
+    dist, comm, exchange = None, None, "one process, no exchange"
+    # rehearsal of the multi-rank path on a one-GPU box: every rank uses device 0 (RCCL refuses two ranks on one device: the
+    # library communicator is then the host-callback kind, its all-gather carried by gloo)
     one_dev = os.environ.get("BNR_BENCH_ONE_DEVICE") == "1"
     if one_dev:
         local_rank = 0
-    # BNR_BENCH_FORCE_DIST=1: take the torch.distributed path also with ONE rank (RCCL communicator, barrier, all-reduce and
-    # all-gather of device tensors on a one-GPU box: the hardware rehearsal of everything in the N > 1 path but the peers)
+    # BNR_BENCH_FORCE_DIST=1: take the multi-rank path also with ONE rank (rendezvous, RCCL communicator, barrier, all-gathers on
+    # a one-GPU box: the hardware rehearsal of everything in the N > 1 path but the peers)
     if a.gpus > 1 or world > 1 or os.environ.get("BNR_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        if one_dev:
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: never depend on what the box's hostname resolves to
-        with _StdoutToStderr():
+        with _StdoutToStderr():                                 # RCCL prints a banner on stdout when a communicator comes up
+            dist.init_process_group("gloo", rank=rank, world_size=world)
             if one_dev:
-                dist.init_process_group("gloo", rank=rank, world_size=world)
+                comm = bnr_amd.make_comm(device=local_rank, force=True)
+                exchange = "bnr_rhat: host-callback communicator over gloo (one-device rehearsal)"
             else:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-            torch.cuda.set_device(local_rank)
-            dist.barrier()                                # creates the communicator (and its banner) now, not in the timed region
-    torch.cuda.set_device(local_rank)
-    red_dev = "cpu" if one_dev else "cuda"               # where the max-over-ranks of the timings is reduced
+                box = [bnr_amd.Comm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                comm = bnr_amd.Comm.rccl(box[0], rank, world, local_rank)
+                exchange = "bnr_rhat: ncclAllGather on the library's RCCL communicator (rendezvous: torch.distributed/gloo)"
+            comm.allgather(np.zeros(8))                         # brings the channels up now, not in the timed region
+            dist.barrier()
+
+    def device_sync():
+        bnr_amd.device_synchronize(local_rank)
+
+    def max_over_ranks(v):
+        return float(comm.allgather(np.array([v])).max()) if comm is not None else v
 
     cfg = CONFIGS[a.config]
     n, V, R = cfg["n"], cfg["V"], cfg["R"]
@@ -151,6 +167,8 @@ def main():
         runner.set_option("overlap", 0)
     if a.graph_k > 0:
         runner.set_option("graph_k", a.graph_k)
+    if not a.graph:
+        runner.set_option("graph", 0)
 
     def run_all(first, last, profile=False):
         if profile:
@@ -167,22 +185,19 @@ def main():
         runner.prepare()
     if W > 0:
         run_all(2, W + 1)
-    torch.cuda.synchronize()
+    device_sync()
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    device_sync()
     t0 = time.perf_counter()
     run_all(W + 2, W + K + 1)
-    torch.cuda.synchronize()
+    device_sync()
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    device_sync()
     dt = time.perf_counter() - t0
     eager_sweeps, replayed_sweeps = runner.last_timing(2)
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt)                                # MAX over ranks (an RCCL all-gather of one double per rank)
 
     # kernel-duration pass: the same sweeps continue, launched eagerly with HIP events recorded around every k_gram launch
     # on the stream it runs on (the timed region above replays captured graphs, where events cannot be read back)
@@ -207,45 +222,29 @@ def main():
         solo = bnr_amd.Chain.like(chains[0], a.seed, ids[0], Ks + 50)
         solo.init_prior()
         solo.run(2, 49, 49)
-        torch.cuda.synchronize()
+        device_sync()
         t1 = time.perf_counter()
         solo.run(50, Ks + 49, Ks + 49)
-        torch.cuda.synchronize()
-        dts = time.perf_counter() - t1
-        if dist:
-            t = torch.tensor([dts], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dts = float(t.item())
+        device_sync()
+        dts = max_over_ranks(time.perf_counter() - t1)
         single = {"value": world * Ks / dts, "unit": "iterations/s", "chains_per_gpu": 1, "steps": Ks, "ms_per_step": 1e3 * dts / Ks}
         solo.close()
 
     # convergence check over all chains of the job (return_psrf_VOI, gibbs.jl:771-789): bnr_rhat -- device reduction per chain, ONE
-    # all-gather of the 4 (q + V)-double messages on the library's own RCCL communicator (ncclAllGather over xGMI; its unique id
-    # travels through torch.distributed), Rhat finished on every rank.  Not timed.  Should the communicator not come up, the
-    # messages go through torch.distributed's all_gather instead and the JSON line says so.
+    # all-gather of the 4 (q + V)-double messages on the library's RCCL communicator (ncclAllGather over xGMI), Rhat finished on
+    # every rank.  Not timed.
     from bnr_amd import _capi
     nsamp = K
-    comm, exchange = None, "one process, no exchange"
-    if dist:
-        try:
-            comm = bnr_amd.make_comm(device=local_rank, force=True)
-            exchange = "bnr_rhat: ncclAllGather on the library's RCCL communicator" if dist.get_backend() == "nccl" else "bnr_rhat: host-callback communicator over gloo"
-        except bnr_amd.BnrError as e:
-            exchange = "torch.distributed all_gather (library communicator unavailable: %s)" % e
     rh = None
     if nsamp >= 4:                                               # split-Rhat needs two samples per half
-        if comm is not None or not dist:
-            rg, rx = _capi.rhat(chains, world * C, comm, W + 1, nsamp)
-            rh = np.concatenate([rg, rx])
-        else:
-            local = {cid: ch.rhat_stats(W + 2, nsamp) for cid, ch in zip(ids, chains)}
-            rh = bnr_amd.rhat_from_stats(bnr_amd.allgather_stats(local, world * C), nsamp)
+        rg, rx = _capi.rhat(chains, world * C, comm, W + 1, nsamp)
+        rh = np.concatenate([rg, rx])
     # effective sample size of the timed window over all chains (an addition to the reference's Rhat; same exchange pattern)
     ess = None
     if nsamp >= 64:
         Lag = min(250, nsamp // 4)
         local_e = {cid: ch.ess_stats(W + 2, nsamp, Lag) for cid, ch in zip(ids, chains)}
-        stats_e = bnr_amd.allgather_stats(local_e, world * C, comm) if dist else np.stack([local_e[c] for c in sorted(local_e)])
+        stats_e = bnr_amd.allgather_stats(local_e, world * C, comm) if comm is not None else np.stack([local_e[c] for c in sorted(local_e)])
         ess = bnr_amd.ess_from_stats(stats_e, nsamp, Lag)
     if comm is not None:
         comm.close()

@@ -52,6 +52,8 @@ typedef void (*bnr_progress_cb)(void *user, int64_t done);
 int bnr_abi_version(void);
 const char *bnr_last_error(void);
 int bnr_device_count(int *count);
+int bnr_device_synchronize(int32_t device);          /* hipDeviceSynchronize on `device` (hosts that hold no HIP binding of their own) */
+int bnr_runtime_version(int *version);               /* hipRuntimeGetVersion of the HIP runtime the library is bound to */
 
 /* Allocate a chain: copies X (n x q col-major) and y to HBM, allocates the tot_save-row state table and all
  * work space on `device`.  Replaces the allocation half of initialize_and_run! (gibbs.jl:822-841).
