@@ -40,6 +40,10 @@ _SIGS = {
     "bnr_runtime_version": (C.c_int, [C.POINTER(C.c_int)]),
     "bnr_chain_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(Hyper), C.c_uint64, C.c_int32,
                                    C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "bnr_chain_create_typed": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, C.c_int32, _dp, C.POINTER(Hyper), C.c_uint64, C.c_int32,
+                                         C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "bnr_chain_create_from_matrices": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, _dp, C.POINTER(Hyper),
+                                                 C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "bnr_chain_create_like": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "bnr_chain_destroy": (C.c_int, [C.c_void_p]),
     "bnr_chain_init_prior": (C.c_int, [C.c_void_p]),
@@ -151,25 +155,63 @@ def runtime_version():
     return v.value
 
 
+X_DTYPES = {np.dtype(np.float64): 0, np.dtype(np.bool_): 1, np.dtype(np.uint8): 1, np.dtype(np.int32): 2, np.dtype(np.int64): 3,
+            np.dtype(np.float32): 4}     # the enum of include/bnr_hip.h (BNR_F64, BNR_U8, BNR_I32, BNR_I64, BNR_F32)
+
+
+class XInput:
+    """The model input of a fit as the library takes it: the n x q matrix X_new in its own element type (gibbs.jl:917:
+    Matrix{eltype(T)} -- Bool adjacency data stays one byte per entry until it is on the device), or, with x_transform=True, the
+    list of n adjacency matrices themselves (setup_X!, gibbs.jl:239-247, then runs on the device).  Element types without a device
+    converter are promoted to float64 here."""
+
+    def __init__(self, X, x_transform=False):
+        self.from_matrices = bool(x_transform)
+        if x_transform:
+            mats = [np.asarray(m) for m in X]
+            V = mats[0].shape[0]
+            if any(m.shape != (V, V) for m in mats):
+                raise ValueError("every adjacency matrix must be V x V")
+            dt = np.result_type(*mats)
+            dt = dt if dt in X_DTYPES else np.dtype(np.float64)
+            self.data = [np.asfortranarray(m, dtype=dt) for m in mats]
+            self.n, self.V = len(mats), V
+            self.q = V * (V + 1) // 2
+        else:
+            a = np.asarray(X)
+            if a.ndim != 2:
+                raise ValueError("X must be an n x q matrix")
+            dt = a.dtype if a.dtype in X_DTYPES else np.dtype(np.float64)
+            self.data = np.asfortranarray(a, dtype=dt)
+            self.n, self.q = a.shape
+            self.V = int(round((-1 + np.sqrt(1 + 8 * self.q)) / 2))
+            if self.V * (self.V + 1) // 2 != self.q:
+                raise ValueError("X must have V(V+1)/2 columns")
+        self.dtype_code = X_DTYPES[dt]
+
+
 class Chain:
     """One Gibbs chain resident on one GPU (handle of include/bnr_hip.h)."""
 
     def __init__(self, X, y, R, tot_save, seed, chain_id, device=0, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0,
                  bDelta=1.0, nu=10):
-        Xf = np.asfortranarray(X, dtype=np.float64)
+        xi = X if isinstance(X, XInput) else XInput(X)
         yf = np.ascontiguousarray(y, dtype=np.float64)
-        n, q = Xf.shape
-        V = int(round((-1 + np.sqrt(1 + 8 * q)) / 2))
-        if V * (V + 1) // 2 != q:
-            raise ValueError("X must have V(V+1)/2 columns")
+        n, q, V = xi.n, xi.q, xi.V
         if yf.shape != (n,):
             raise ValueError("y must have one entry per row of X")
         self.n, self.q, self.V, self.R, self.tot = n, q, V, int(R), int(tot_save)
         self.h = C.c_void_p()
         hy = Hyper(eta, zeta, iota, aDelta, bDelta, float(nu))
         self.L = lib()
-        check(self.L.bnr_chain_create(n, V, int(R), _ptr(Xf), _ptr(yf), C.byref(hy), C.c_uint64(int(seed) & (2**64 - 1)),
-                                      int(chain_id), int(device), int(tot_save), C.byref(self.h)))
+        common = (_ptr(yf), C.byref(hy), C.c_uint64(int(seed) & (2**64 - 1)), int(chain_id), int(device), int(tot_save), C.byref(self.h))
+        if xi.from_matrices:
+            ptrs = (C.c_void_p * n)(*[m.ctypes.data for m in xi.data])
+            check(self.L.bnr_chain_create_from_matrices(n, V, int(R), ptrs, xi.dtype_code, *common))
+        elif xi.dtype_code == 0:
+            check(self.L.bnr_chain_create(n, V, int(R), _ptr(xi.data), *common))
+        else:
+            check(self.L.bnr_chain_create_typed(n, V, int(R), _ptr(xi.data), xi.dtype_code, *common))
 
     @classmethod
     def like(cls, donor, seed, chain_id, tot_save=None):

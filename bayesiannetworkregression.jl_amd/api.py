@@ -27,7 +27,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _capi
-from ._capi import Chain, Comm, Group, ess_from_stats, new_table, rhat_from_stats
+from ._capi import Chain, Comm, Group, XInput, ess_from_stats, new_table, rhat_from_stats
 
 CITATION = ("If you use BayesianNetworkRegression.jl, please cite:\n@article{Ozminkowski2022,\n"
             "author = {Ozminkowski, S. and Sol\\'{i}s-Lemus, C.},\nyear = {2022},\n"
@@ -277,7 +277,7 @@ class ChainSet:
         self.group = Group([self.chains[c] for c in self.ids]) if len(self.chains) > 1 else None
         self.V, self.q, self.R = (next(iter(self.chains.values())).V, next(iter(self.chains.values())).q, R) if self.chains else (None, None, R)
         if self.V is None:                                  # a rank without a chain still takes part in the exchanges
-            self.q = int(np.asarray(X_new).shape[1])
+            self.q = X_new.q if isinstance(X_new, XInput) else int(np.asarray(X_new).shape[1])
             self.V = int((-1 + math.sqrt(1 + 8 * self.q)) / 2)
         self.comm = make_comm(dev)
 
@@ -403,7 +403,7 @@ def generate_samples(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDelta=1
         pass                                       # the reference constructs an ArgumentError without throwing it (901-902)
     elif nu == R:
         print("Warning: ν==R may give poor accuracy. Consider increasing ν")
-    X_new, V, q = setup_X(X, x_transform)
+    X_new = XInput(X, x_transform)                 # X_new of gibbs.jl:907-918: element type kept, setup_X! runs on the device
     y = np.asarray(y, dtype=np.float64)
     total = nburn + nsamp
     prog_freq = 1000
@@ -459,7 +459,7 @@ def generate_samples_dbl(X, y, R, eta=1.01, zeta=1.0, iota=1.0, aDelta=1.0, bDel
         print("Warning: ν==R may give poor accuracy. Consider increasing ν")
     nburn = _julia_round(mingen / 2)
     nsamp = mingen - nburn
-    X_new, V, q = setup_X(X, x_transform)
+    X_new = XInput(X, x_transform)
     y = np.asarray(y, dtype=np.float64)
     total = nburn + nsamp
     prog_freq = 1000

@@ -118,6 +118,7 @@ static int ensure_lds_attributes(int device)
 extern "C" {
 
 static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape);
+static int check_launch(const char *what);
 static void exec_free(bnr_exec &x);
 static int sync_dev(bnr_chain *c);
 
@@ -171,11 +172,56 @@ static int alloc_trace(bnr_chain *c, int tot, double **out)
     return BNR_OK;
 }
 
+// Where the model matrix comes from: the n x q matrix X_new of generate_samples! (gibbs.jl:917-918) in one of the element types
+// the reference accepts (Matrix{eltype(T)}: Bool, Int, Float64 ...), or the vector of n adjacency matrices itself, vectorised on
+// the device (setup_X!, gibbs.jl:239-247: row i = lower_triangle(X[i]), utils.jl:40-57).
+struct x_source {
+    const void *X = nullptr;               // n x q column-major (mats == nullptr)
+    const void *const *mats = nullptr;     // n pointers to V x V column-major matrices
+    int dtype = BNR_F64;
+};
+static size_t dtype_size(int t) { return t == BNR_U8 ? 1 : (t == BNR_I32 || t == BNR_F32) ? 4 : 8; }
+// raw (host layout, any element type) -> the padded f64 device matrix; the conversion runs on the device
+static int upload_x(bnr_chain *c, const x_source &src, double *Xd)
+{
+    const bnr_dev &d = c->d;
+    const size_t es = dtype_size(src.dtype);
+    if (!src.mats && src.dtype == BNR_F64) {
+        HIPCHK(hipMemcpy2D(Xd, (size_t)d.n_pad * sizeof(double), src.X, (size_t)d.n * sizeof(double), (size_t)d.n * sizeof(double), d.q, hipMemcpyHostToDevice));
+        return BNR_OK;
+    }
+    const size_t count = src.mats ? (size_t)d.n * d.V * d.V : (size_t)d.n * d.q;
+    void *raw = nullptr;
+    HIPCHK(hipMalloc(&raw, count * es));
+    hipError_t e = hipSuccess;
+    if (src.mats) {
+        for (int i = 0; i < d.n && e == hipSuccess; ++i) {
+            if (!src.mats[i]) { hipFree(raw); return fail(BNR_ERR_BAD_ARG, "NULL adjacency matrix"); }
+            e = hipMemcpyAsync((char *)raw + (size_t)i * d.V * d.V * es, src.mats[i], (size_t)d.V * d.V * es, hipMemcpyHostToDevice, c->x.stream);
+        }
+    } else e = hipMemcpyAsync(raw, src.X, count * es, hipMemcpyHostToDevice, c->x.stream);
+    if (e == hipSuccess) {
+        const dim3 grid((d.n + 63) / 64, std::min(d.q, 65535)), block(64);
+        switch (src.dtype) {
+        case BNR_U8:  hipLaunchKernelGGL(k_x_convert<uint8_t>, grid, block, 0, c->x.stream, (const uint8_t *)raw, src.mats != nullptr, d.n, d.V, d.q, d.n_pad, d.ek, d.el, Xd); break;
+        case BNR_I32: hipLaunchKernelGGL(k_x_convert<int32_t>, grid, block, 0, c->x.stream, (const int32_t *)raw, src.mats != nullptr, d.n, d.V, d.q, d.n_pad, d.ek, d.el, Xd); break;
+        case BNR_I64: hipLaunchKernelGGL(k_x_convert<int64_t>, grid, block, 0, c->x.stream, (const int64_t *)raw, src.mats != nullptr, d.n, d.V, d.q, d.n_pad, d.ek, d.el, Xd); break;
+        case BNR_F32: hipLaunchKernelGGL(k_x_convert<float>, grid, block, 0, c->x.stream, (const float *)raw, src.mats != nullptr, d.n, d.V, d.q, d.n_pad, d.ek, d.el, Xd); break;
+        default:      hipLaunchKernelGGL(k_x_convert<double>, grid, block, 0, c->x.stream, (const double *)raw, src.mats != nullptr, d.n, d.V, d.q, d.n_pad, d.ek, d.el, Xd); break;
+        }
+        e = hipStreamSynchronize(c->x.stream);
+    }
+    hipFree(raw);
+    if (e != hipSuccess) return fail(BNR_ERR_HIP, std::string("upload of X: ") + hipGetErrorString(e));
+    return check_launch("k_x_convert");
+}
+
 // donor != NULL: share the donor's device inputs instead of uploading X, y (bnr_chain_create_like)
-static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, const double *X, const double *y, const bnr_hyper *hyper,
+static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, const x_source &xs, const double *y, const bnr_hyper *hyper,
                        uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save, bnr_chain **out)
 {
-    if (!out || !hyper || (!donor && (!X || !y))) return fail(BNR_ERR_BAD_ARG, "NULL argument");
+    if (!out || !hyper || (!donor && ((!xs.X && !xs.mats) || !y))) return fail(BNR_ERR_BAD_ARG, "NULL argument");
+    if (xs.dtype < BNR_F64 || xs.dtype > BNR_F32) return fail(BNR_ERR_BAD_ARG, "unknown element type of X");
     if (n < 1 || V < 2 || R < 1 || R > BNR_RMAX || tot_save < 2)
         return fail(BNR_ERR_BAD_ARG, "need n>=1, V>=2, 1<=R<=32, tot_save>=2");
     // LDS budgets of the kernels that stage a whole vector / the R x V matrix u: k_tail keeps u (R V doubles) next to 33 KiB of
@@ -271,8 +317,6 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
         TRY(in_alloc((void **)&yd, sizeof(double) * d.n_pad));
         TRY(in_alloc((void **)&ek, sizeof(int) * d.q));
         TRY(in_alloc((void **)&el, sizeof(int) * d.q));
-        if (hipMemcpy2D(Xd, (size_t)d.n_pad * sizeof(double), X, (size_t)n * sizeof(double), (size_t)n * sizeof(double), d.q,
-                        hipMemcpyHostToDevice) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "copy X failed"); }
         if (hipMemcpy(yd, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "copy y failed"); }
         {
             std::vector<int> hk(d.q), hl(d.q);
@@ -281,6 +325,8 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
             hipMemcpy(ek, hk.data(), d.q * sizeof(int), hipMemcpyHostToDevice);
             hipMemcpy(el, hl.data(), d.q * sizeof(int), hipMemcpyHostToDevice);
         }
+        d.ek = ek; d.el = el;
+        TRY(upload_x(c, xs, Xd));
         {
             // XCD-aware task map of k_gram (tasks = lower tiles x K slices): workgroup i runs on XCD i % 8; give it a K
             // slice ks with ks % 8 == i % 8 while there are any, so that a slice of X is read through one XCD's L2
@@ -342,14 +388,22 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
 
 int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const double *y, const bnr_hyper *hyper,
                      uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save, bnr_chain **out)
-{ return chain_build(nullptr, n, V, R, X, y, hyper, seed, chain_id, device, tot_save, out); }
+{ x_source xs; xs.X = X; return chain_build(nullptr, n, V, R, xs, y, hyper, seed, chain_id, device, tot_save, out); }
+
+int bnr_chain_create_typed(int32_t n, int32_t V, int32_t R, const void *X, int32_t x_dtype, const double *y, const bnr_hyper *hyper,
+                           uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save, bnr_chain **out)
+{ x_source xs; xs.X = X; xs.dtype = x_dtype; return chain_build(nullptr, n, V, R, xs, y, hyper, seed, chain_id, device, tot_save, out); }
+
+int bnr_chain_create_from_matrices(int32_t n, int32_t V, int32_t R, const void *const *A, int32_t x_dtype, const double *y, const bnr_hyper *hyper,
+                                   uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save, bnr_chain **out)
+{ x_source xs; xs.mats = A; xs.dtype = x_dtype; return chain_build(nullptr, n, V, R, xs, y, hyper, seed, chain_id, device, tot_save, out); }
 
 int bnr_chain_create_like(const bnr_chain *donor, uint64_t seed, int32_t chain_id, int32_t tot_save, bnr_chain **out)
 {
     if (!donor) return fail(BNR_ERR_BAD_ARG, "NULL donor chain");
     const bnr_dev &a = donor->d;
     bnr_hyper h{a.eta, a.zeta, a.iota, a.aDelta, a.bDelta, a.nu};
-    return chain_build(donor, a.n, a.V, a.R, nullptr, nullptr, &h, seed, chain_id, donor->device, tot_save, out);
+    return chain_build(donor, a.n, a.V, a.R, x_source(), nullptr, &h, seed, chain_id, donor->device, tot_save, out);
 }
 
 static void drop_graph(bnr_exec &x)

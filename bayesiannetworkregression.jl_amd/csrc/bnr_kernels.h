@@ -1523,6 +1523,22 @@ __global__ __launch_bounds__(256) void k_init_prior(bnr_dev cd)
     if (cap) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
 }
 
+// ===================================================================================== model matrix from the caller's element type
+// X[i, e] (f64, leading dimension n_pad) from the host layout uploaded as it is: either the n x q matrix X_new of
+// generate_samples! in its own element type (gibbs.jl:917: Matrix{eltype(T)} -- Bool for adjacency data), or the n adjacency
+// matrices themselves (V x V column-major, one after the other): setup_X! on the device (gibbs.jl:239-247), row i =
+// lower_triangle(A_i), i.e. edge e <-> (l >= k) reads A_i[l, k] (utils.jl:50-55).  grid = (ceil(n/64), edges), 64 threads.
+template <typename T>
+__global__ void k_x_convert(const T *raw, bool from_matrices, int n, int V, int q, int n_pad, const int *ek, const int *el, double *X)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    for (int e = blockIdx.y; e < q; e += gridDim.y) {
+        const T v = from_matrices ? raw[(size_t)i * V * V + (size_t)el[e] + (size_t)V * ek[e]] : raw[(size_t)i + (size_t)n * e];
+        X[(size_t)i + (size_t)n_pad * e] = (double)v;
+    }
+}
+
 // ===================================================================================== table transposes
 // out[r + nrows*d] = trace[(first + r)*rowlen + off + d]   (device row-major -> reference iteration-fastest)
 __global__ void k_fetch_cols(const double *trace, int rowlen, int off, int ncols, int first, int nrows, double *out)

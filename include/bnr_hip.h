@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define BNR_ABI_VERSION 4   /* 2: + bnr_chain_create_like, bnr_group_*, bnr_chain_summary; 3: + bnr_*_prepare; 4: + bnr_comm_*, bnr_rhat (additive) */
+#define BNR_ABI_VERSION 5   /* 2: + bnr_chain_create_like, bnr_group_*, bnr_chain_summary; 3: + bnr_*_prepare; 4: + bnr_comm_*, bnr_rhat;
+                               5: + bnr_chain_create_typed, bnr_chain_create_from_matrices, bnr_device_synchronize (all additive) */
 
 enum {
     BNR_OK = 0,
@@ -61,6 +62,18 @@ int bnr_runtime_version(int *version);               /* hipRuntimeGetVersion of 
  * Limits (BNR_ERR_BAD_ARG otherwise): 1 <= R <= 32, V >= 2, R*V <= 15360, n <= 14000 (LDS budgets of single-workgroup kernels). */
 int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const double *y, const bnr_hyper *hyper,
                      uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save, bnr_chain **out);
+/* The same with the model matrix in the caller's own element type -- the reference builds X_new as Matrix{eltype(T)} (gibbs.jl:917:
+ * Bool for 0/1 adjacency data, Int, Float64 ...) -- uploaded as it is (a Bool/UInt8 matrix is 1/8 of the PCIe traffic) and converted
+ * to the f64 device layout by a kernel.  X: n x q column-major elements of x_dtype. */
+enum { BNR_F64 = 0, BNR_U8 = 1 /* Julia Bool / UInt8 */, BNR_I32 = 2, BNR_I64 = 3 /* Julia Int */, BNR_F32 = 4 };
+int bnr_chain_create_typed(int32_t n, int32_t V, int32_t R, const void *X, int32_t x_dtype, const double *y, const bnr_hyper *hyper,
+                           uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save, bnr_chain **out);
+/* ... and straight from the vector of n adjacency matrices (x_transform = true: setup_X!, gibbs.jl:239-247, runs on the device):
+ * A[i] points at a V x V column-major matrix of x_dtype; row i of the model matrix is lower_triangle(A[i]) (utils.jl:40-57: the
+ * column-wise lower triangle including the diagonal, reading A[i][l, k] for l >= k -- the matrices need not be symmetric). */
+int bnr_chain_create_from_matrices(int32_t n, int32_t V, int32_t R, const void *const *A, int32_t x_dtype, const double *y,
+                                   const bnr_hyper *hyper, uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save,
+                                   bnr_chain **out);
 /* Another chain of the same fit on the same device: same X, y, sizes and hyper-parameters as `donor`, own seed /
  * chain id, own table and work space.  The read-only device inputs (X, y, index maps) are SHARED with the donor, not
  * copied -- the reference hands the same X, y to every pmap worker (gibbs.jl:946-948) -- and live until the last chain

@@ -521,6 +521,98 @@ def test_generate_samples_end_to_end(gpu, test1, tmp_path):
     assert r3.burn_in == 10 and r3.sampled == 20 and r3.state["gamma"].shape[0] == 30
 
 
+def _oracle_doubling(X, y, R, mingen, rounds, seed, chain):
+    """generate_samples_dbl! (gibbs.jl:1051-1198) walked by the oracle for ONE chain: first pass nburn = round(mingen/2),
+    nsamp = mingen - nburn; then `rounds` doubling rounds -- a NEW table of tot_samples + halfburn rows, the last num2move rows
+    of the old one copied to its head (copy_table!, :1172), run! from num2move + 1 with nburn = 0 (:1176-1178)."""
+    nburn = int(round(mingen / 2))
+    nsamp = mingen - nburn
+    tot_save = nburn + nsamp
+    o = bo.Oracle(X, y, R, tot_save, seed, chain=chain, pdf_mode=1)
+    o.init_prior()
+    o.run(2, nburn, tot_save)
+    tot_samples = nsamp
+    for _ in range(rounds):
+        halfburn = int(round(mingen / 2))
+        num2move = tot_samples
+        tot_samples += halfburn
+        nsamp = tot_samples
+        tot_sze, tot_save = tot_save, tot_samples + halfburn
+        new = bo.new_table(tot_save, o.V, R)
+        for k in bo.COLUMNS:
+            new[k][:num2move] = o.t[k][tot_sze - num2move:tot_sze]
+        it = o.iter
+        o = bo.Oracle(X, y, R, tot_save, seed, chain=chain, pdf_mode=1, table=new)
+        o.iter = it
+        assert o.run(num2move + 1, 0, tot_save) == tot_save + 1
+    return o.t, nburn, nsamp
+
+
+def test_doubling_scheme_walks_the_same_rows_as_the_oracle(gpu, test1, capfd):
+    """generate_samples_dbl! (gibbs.jl:1051-1198; Fit! with mingen, maxgen): an unreachable PSRF cutoff forces exactly two doubling
+    rounds (maxgen = 3 mingen); chain 1's final table, burn_in / sampled and the PSRF over both chains equal what the oracle
+    produces walking the reference's row-moving arithmetic (num2move, re-allocated table, first_index) -- also with an odd mingen."""
+    X, y = test1
+    for mingen in (24, 15):
+        res = bnr_amd.generate_samples_dbl(X, y, 5, mingen=mingen, maxgen=3 * mingen, psrf_cutoff=0.5, x_transform=False,
+                                           suppress_timer=True, num_chains=2, seed=321)
+        err = capfd.readouterr().err
+        tabs = [_oracle_doubling(X, y, 5, mingen, 2, 321, c) for c in (1, 2)]
+        t1, nburn, nsamp = tabs[0]
+        assert res.burn_in == nburn and res.sampled == nsamp and res.state["gamma"].shape[0] == nburn + nsamp == t1["gamma"].shape[0]
+        assert_tables_close(res.state, t1, what="doubling scheme, mingen=%d" % mingen)
+        g = np.stack([t[0]["gamma"][nburn:nburn + nsamp, :, 0] for t in tabs], axis=2)
+        x = np.stack([t[0]["xi"][nburn:nburn + nsamp, :, 0] for t in tabs], axis=2)
+        assert np.allclose(res.rhatgamma, bo.rhat(g), rtol=1e-6) and np.allclose(res.rhatxi, bo.rhat(x), rtol=1e-6, equal_nan=True)
+        hb = int(round(mingen / 2))
+        first = mingen - hb
+        assert "num2move: %d nburn: %d nsamp: %d tot_save: %d first_index: %d" % (first, hb, first + hb, first + 2 * hb, first + 1) in err
+        assert "%d samples generated" % (3 * mingen) in err
+
+
+def test_input_formats_are_converted_on_the_device(gpu):
+    """The inputs generate_samples! accepts (gibbs.jl:907-918, docs/src/man/inputdata.md:5-10): X_new keeps the element type of the
+    data (Matrix{eltype(T)}: Bool for 0/1 adjacency matrices, Int counts, Float32/64), and with x_transform=true X is the vector of
+    adjacency matrices that setup_X! (gibbs.jl:239-247) vectorises by lower_triangle (utils.jl:40-57: A[l, k], l >= k, so a matrix
+    that is only lower-triangular gives the same row).  Here the raw bytes are uploaded and converted / vectorised on the device:
+    every variant must give the table of the float64 n x q matrix bit for bit."""
+    rng = np.random.default_rng(5)
+    n, V, R, tot = 37, 9, 3, 8
+    mats_bool = [np.tril(rng.random((V, V)) < 0.5) for _ in range(n)]                  # lower-triangular Bool, like examples/data*.csv
+    mats_int = [np.tril(rng.integers(0, 6, (V, V))) + np.triu(rng.integers(0, 6, (V, V)), 1) for _ in range(n)]   # not symmetric
+    y = rng.normal(size=n)
+
+    def table(X, x_transform):
+        ch = bnr_amd.Chain(bnr_amd.XInput(X, x_transform), y, R, tot, 11, 1)
+        ch.init_prior()
+        ch.run(2, tot, tot)
+        t = ch.fetch()
+        ch.close()
+        return t
+
+    for mats in (mats_bool, mats_int):
+        Xh, Vh, qh = bnr_amd.setup_X(mats, True)                                      # host restatement of setup_X!
+        assert (Vh, qh) == (V, V * (V + 1) // 2)
+        want = table(Xh, False)
+        variants = {"matrices": (mats, True), "matrices f32": ([m.astype(np.float32) for m in mats], True),
+                    "matrix own dtype": (Xh.astype(mats[0].dtype), False), "matrix int32": (Xh.astype(np.int32), False),
+                    "matrix uint8": (Xh.astype(np.uint8), False), "matrix f32": (Xh.astype(np.float32), False),
+                    "matrix int16 (promoted on the host)": (Xh.astype(np.int16), False)}
+        for name, (X, tr) in variants.items():
+            got = table(X, tr)
+            for k in bo.COLUMNS:
+                assert np.array_equal(got[k], want[k]), (name, k)
+    o = bo.Oracle(bnr_amd.setup_X(mats_int, True)[0], y, R, tot, 11, chain=1, pdf_mode=1)
+    o.init_prior()
+    o.run(2, tot, tot)
+    assert_tables_close(table(mats_int, True), o.t, what="integer adjacency matrices vs oracle")
+    # the drop-in entry point takes the vector of matrices as the reference does (x_transform = true is its default)
+    res = bnr_amd.generate_samples(mats_bool, y, R, nburn=6, nsamp=4, maxburn=6, psrf_cutoff=10.0, suppress_timer=True, num_chains=2, seed=10)
+    assert res.state["gamma"].shape == (10, V * (V + 1) // 2, 1)
+    with pytest.raises(ValueError):
+        bnr_amd.XInput([np.zeros((3, 3)), np.zeros((4, 4))], True)
+
+
 def test_device_summary_equals_host_summary(gpu, test1):
     """bnr_chain_summary (Summary on the device, gibbs.jl:1214-1250): the posterior means agree with the host to rounding,
     the order statistics are EXACTLY the entries of the sorted trace the reference indexes -- also with ties, negative
