@@ -52,6 +52,21 @@ print(done - 1, time.time() - t0, threads, mode, "|", blas or "")
 """
 
 
+def host_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box shows all 256 hardware
+    threads of its host, but its share per GPU is 16 cores -- oversubscribing spinning BLAS/OpenMP threads would understate the
+    CPU baseline several-fold)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    cap = os.environ.get("BNR_BENCH_CPUS")
+    return max(1, min(n, int(cap))) if cap else n
+
+
 def cpu_baseline(n, V, R, seed, nchains, budget_s=15.0, mode=2):
     """The CPU oracle in reference-cost mode on the host cores: the same `nchains` chains as one OS process each (the reference's
     pmap workers, gibbs.jl:946), the host's hardware threads divided among them; iterations/s summed over the chains.
@@ -59,7 +74,7 @@ def cpu_baseline(n, V, R, seed, nchains, budget_s=15.0, mode=2):
               (numpy's bundled libscipy_openblas: the reference's Julia links OpenBLAS too), dense (V-1)-dim pdfs;
       mode 1: the same operation counts with the oracle's own plain-C loops (OpenMP over the Gram columns), no BLAS."""
     import subprocess
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncpu = host_cpus()
     per = max(1, min(64, ncpu // nchains))                  # numpy's OpenBLAS is built with MAX_THREADS = 64
     env = dict(os.environ, OMP_NUM_THREADS=str(per), OPENBLAS_NUM_THREADS=str(per))
     procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, str(n), str(V), str(R), str(seed), str(c + 1), str(budget_s), str(mode), str(per)],
@@ -254,7 +269,7 @@ def main():
         value = total_chains * K / dt
         flops_gram = float(n) * n * q * C                         # algorithmic: symmetric X diag(S) X'  per chain of the launch
         traffic = None                                            # HBM bytes per k_gram launch from the PMC passes (tools/pmc_gram2.sh)
-        pmc_file = os.path.join(ROOT, "profiles", "round1_gram_pmc_kg2.json")
+        pmc_file = os.path.join(ROOT, "profiles", "round2_gram_pmc.json")
         if a.config == "cfg3" and C in (1, 8) and os.path.exists(pmc_file):
             traffic = json.load(open(pmc_file))["one" if C == 1 else "group8"].get("traffic_bytes_per_launch")
         achieved = flops_gram / (gram_us * 1e-6) / 1e12 if gram_us > 0 else 0.0
@@ -272,7 +287,7 @@ def main():
             "timed_region": {"sweeps_replayed_from_graphs": int(replayed_sweeps), "sweeps_launched_eagerly": int(eager_sweeps)},
             "roofline": {"bound": "mfma", "kernel": "k_gram (X diag(S) X', v_mfma_f64_16x16x4_f64)", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_source": "profiles/round1_gram_pmc_kg2.json (FETCH_SIZE x2 + WRITE_SIZE of a launch of this shape, separate --pmc passes, tools/pmc_gram_group.sh)",
+                         "traffic": traffic, "traffic_source": "profiles/round2_gram_pmc.json (FETCH_SIZE x2 + WRITE_SIZE of a launch of this shape, separate --pmc passes, tools/pmc_gram_group.sh)",
                          "sweep_frac": sweep_tflops / FP64_MFMA_PEAK_TFLOPS, "sweep_achieved": sweep_tflops, "sweep_flops_per_chain_iteration": f_iter,
                          "flops_per_launch": flops_gram, "avg_launch_us": gram_us, "launches_timed": gram_n,
                          "avg_launch_us_two_branch_schedule": gram_us_pipe,

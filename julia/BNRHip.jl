@@ -1,16 +1,22 @@
 # BNRHip.jl -- thin Julia shim over libbnr_hip.so (include/bnr_hip.h).
 #
-# Drop-in for the Gibbs hot path of BayesianNetworkRegression.jl: it provides `initialize_and_run!`-level and
-# `generate_samples!`-level entry points with the reference's argument meaning, and returns the reference's own
-# `Results(state::Table, rhatξ::Table, rhatγ::Table, burn_in, sampled)` (src/gibbs.jl:23-29), so `Summary` and
-# `show` of the package work unchanged.  No logic lives here: every sampling step is a `ccall`.
+# Drop-in for the Gibbs hot path of BayesianNetworkRegression.jl: `generate_samples!` with the reference's argument meaning
+# (src/gibbs.jl:897-1020, including the PSRF-driven top-up rounds) returning the reference's own
+# `Results(state::Table, rhatξ::Table, rhatγ::Table, burn_in, sampled)` (src/gibbs.jl:23-29), so `Summary` and `show` of the
+# package work unchanged.  No sampling logic lives here: every step is a `ccall`; what remains is the reference's schedule
+# arithmetic (num2move, first_index), kept line for line with gibbs.jl:962-1013.
 #
-# NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no `julia` binary.  The same C ABI is exercised by the
-# Python/ctypes mirror (bayesiannetworkregression.jl_amd/_capi.py, api.py) in tests/.
+# Chains and GPUs: the chains of this process live on ONE GPU and advance as a lockstep group (bnr_group_run replaces the pmap
+# over chains, gibbs.jl:946-948).  With several GPUs start one Julia worker per GPU (`addprocs(ngpu)`, worker w drives device
+# w-1) and hand every worker the same `comm` description (see `rccl_comm`): chains are placed round-robin, (c-1) % world == rank,
+# and `bnr_rhat` all-gathers the per-chain messages over the library's own RCCL communicator.
+#
+# NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no `julia` binary.  The same C ABI, call for call, is exercised by
+# the Python/ctypes mirror (bayesiannetworkregression.jl_amd/_capi.py, api.py) in tests/.
 module BNRHip
 
 using TypedTables, Random
-import BayesianNetworkRegression: Results, lower_triangle, setup_X!
+import BayesianNetworkRegression: Results
 
 const LIB = get(ENV, "BNR_HIP_LIB", joinpath(@__DIR__, "..", "bayesiannetworkregression.jl_amd", "libbnr_hip.so"))
 
@@ -21,21 +27,45 @@ end
 lasterr() = unsafe_string(ccall((:bnr_last_error, LIB), Cstring, ()))
 check(rc) = rc == 0 || error("libbnr_hip: $(lasterr()) (status $rc)")
 
+# element types the library converts on the device (enum of include/bnr_hip.h); anything else is promoted to Float64 here
+dtype_code(::Type{Float64}) = 0
+dtype_code(::Type{Bool}) = 1
+dtype_code(::Type{UInt8}) = 1
+dtype_code(::Type{Int32}) = 2
+dtype_code(::Type{Int64}) = 3
+dtype_code(::Type{Float32}) = 4
+dtype_code(::Type) = -1
+
 mutable struct Chain
     h::Ptr{Cvoid}
     n::Int; V::Int; R::Int; q::Int; tot::Int
 end
+destroy(ch::Chain) = ccall((:bnr_chain_destroy, LIB), Cint, (Ptr{Cvoid},), ch.h)
 
-function Chain(X::Matrix{Float64}, y::Vector{Float64}, R, tot_save, seed, c; η=1.01, ζ=1.0, ι=1.0, aΔ=1.0, bΔ=1.0, ν=10, device=0)
-    n, q = size(X)
-    V = Int64((-1 + sqrt(1 + 8 * q)) / 2)
+# X: the vector of n adjacency matrices (x_transform = true; setup_X!, gibbs.jl:239-247, runs on the device) or the n x q matrix
+# X_new (gibbs.jl:917-918) in its own element type
+function Chain(X, y::Vector{Float64}, R, tot_save, seed, c; x_transform=true, η=1.01, ζ=1.0, ι=1.0, aΔ=1.0, bΔ=1.0, ν=10, device=0)
     hy = Ref(Hyper(η, ζ, ι, aΔ, bΔ, ν))
     out = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve X y check(ccall((:bnr_chain_create, LIB), Cint,
-        (Int32, Int32, Int32, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Hyper}, UInt64, Int32, Int32, Int32, Ref{Ptr{Cvoid}}),
-        n, V, R, X, y, hy, UInt64(seed), c, device, tot_save, out))
-    ch = Chain(out[], n, V, R, q, tot_save)
-    finalizer(x -> ccall((:bnr_chain_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), ch)
+    if x_transform
+        T = dtype_code(eltype(X[1])) >= 0 ? eltype(X[1]) : Float64
+        mats = [Matrix{T}(m) for m in X]                       # column-major V x V each
+        n, V = length(mats), size(mats[1], 1)
+        ptrs = [Ptr{Cvoid}(pointer(m)) for m in mats]
+        GC.@preserve mats ptrs y check(ccall((:bnr_chain_create_from_matrices, LIB), Cint,
+            (Int32, Int32, Int32, Ptr{Ptr{Cvoid}}, Int32, Ptr{Cdouble}, Ref{Hyper}, UInt64, Int32, Int32, Int32, Ref{Ptr{Cvoid}}),
+            n, V, R, ptrs, dtype_code(T), y, hy, UInt64(seed), c, device, tot_save, out))
+    else
+        T = dtype_code(eltype(X)) >= 0 ? eltype(X) : Float64
+        Xm = Matrix{T}(X)
+        n, q = size(Xm)
+        V = Int64((-1 + sqrt(1 + 8 * q)) / 2)
+        GC.@preserve Xm y check(ccall((:bnr_chain_create_typed, LIB), Cint,
+            (Int32, Int32, Int32, Ptr{Cvoid}, Int32, Ptr{Cdouble}, Ref{Hyper}, UInt64, Int32, Int32, Int32, Ref{Ptr{Cvoid}}),
+            n, V, R, Xm, dtype_code(T), y, hy, UInt64(seed), c, device, tot_save, out))
+    end
+    ch = Chain(out[], n, V, R, V * (V + 1) ÷ 2, tot_save)
+    finalizer(destroy, ch)
     ch
 end
 
@@ -44,20 +74,15 @@ function chain_like(donor::Chain, seed, c, tot_save=donor.tot)
     out = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:bnr_chain_create_like, LIB), Cint, (Ptr{Cvoid}, UInt64, Int32, Int32, Ref{Ptr{Cvoid}}), donor.h, UInt64(seed), c, tot_save, out))
     ch = Chain(out[], donor.n, donor.V, donor.R, donor.q, tot_save)
-    finalizer(x -> ccall((:bnr_chain_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), ch)
+    finalizer(destroy, ch)
     ch
 end
 
 init_prior!(ch::Chain) = check(ccall((:bnr_chain_init_prior, LIB), Cint, (Ptr{Cvoid},), ch.h))
-
-# Summary statistics on the device (gibbs.jl:1214-1250): (mean γ, lower, upper, P(ξ=1)); ranks are 1-based positions in the sorted sample
-function summary_stats(ch::Chain, nburn, nsamp; interval=95)
-    lb = (100 - interval) / 200
-    klo, khi = Int(round(nsamp * lb)), Int(round(nsamp * (1 - lb)))
-    m, lo, hi, p = zeros(ch.q), zeros(ch.q), zeros(ch.q), zeros(ch.V)
-    check(ccall((:bnr_chain_summary, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
-        ch.h, nburn + 1, nsamp, klo, khi, m, lo, hi, p))
-    m, lo, hi, p
+move_rows!(ch::Chain, to, from, count) = check(ccall((:bnr_chain_move_rows, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32), ch.h, to, from, count))
+function resize_table!(ch::Chain, new_tot)
+    check(ccall((:bnr_chain_resize, LIB), Cint, (Ptr{Cvoid}, Int32), ch.h, new_tot))
+    ch.tot = new_tot
 end
 
 # lockstep group: the chains of one fit that share a GPU advance together (replaces the pmap over chains, gibbs.jl:946-948)
@@ -73,22 +98,21 @@ function Group(chains::Vector{Chain})
     finalizer(x -> ccall((:bnr_group_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), g)
     g
 end
-function run!(g::Group, first_index, nburn, total, purge_burn; prog_freq=0, tick=nothing)
-    nxt = Ref{Int32}(0)
-    cb = tick === nothing ? C_NULL : @cfunction((u, d) -> (tick(); nothing), Cvoid, (Ptr{Cvoid}, Int64))
-    check(ccall((:bnr_group_run, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}),
-        g.h, first_index, nburn, total, isnothing(purge_burn) ? 0 : purge_burn, prog_freq, cb, C_NULL, nxt))
-    Int(nxt[])
-end
 
-# run!(X,y,state,c,first_index,nburn,total,...,purge_burn,channel)  (gibbs.jl:849-864)
-function run!(ch::Chain, first_index, nburn, total, purge_burn; prog_freq=0, tick=nothing)
+# run!(X,y,state,c,first_index,nburn,total,...,purge_burn,channel) (gibbs.jl:849-864) for every chain of the group / for one chain;
+# `tick` is called every prog_freq iterations like the reference's put!(channel, true) of chain 1 (gibbs.jl:854-856)
+const TICK = Ref{Any}(nothing)
+tick_trampoline(::Ptr{Cvoid}, ::Int64) = (TICK[] === nothing || TICK[](); nothing)
+function run!(x::Union{Group,Chain}, first_index, nburn, total, purge_burn; prog_freq=0, tick=nothing)
     nxt = Ref{Int32}(0)
-    cb = tick === nothing ? C_NULL : @cfunction((u, d) -> (tick(); nothing), Cvoid, (Ptr{Cvoid}, Int64))
-    check(ccall((:bnr_chain_run, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}),
-        ch.h, first_index, nburn, total, isnothing(purge_burn) ? 0 : purge_burn, prog_freq, cb, C_NULL, nxt))
+    TICK[] = tick
+    cb = tick === nothing ? C_NULL : @cfunction(tick_trampoline, Cvoid, (Ptr{Cvoid}, Int64))
+    f = x isa Group ? :bnr_group_run : :bnr_chain_run
+    check(ccall((f, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}),
+        x.h, first_index, nburn, total, isnothing(purge_burn) ? 0 : purge_burn, tick === nothing ? 0 : prog_freq, cb, C_NULL, nxt))
     Int(nxt[])
 end
+prepare!(g::Group) = check(ccall((:bnr_group_prepare, LIB), Cint, (Ptr{Cvoid},), g.h))   # optional: captures the replayed graphs now
 
 # the reference's 14-column state Table (gibbs.jl:835-841); the 3 dead columns stay undef as in the reference
 function new_table(tot, V, R)
@@ -112,40 +136,89 @@ function fetch!(state::Table, ch::Chain, first_row=1, last_row=ch.tot)
     state
 end
 
-function rhat_stats(ch::Chain, first_row, nsamp)
-    out = Vector{Float64}(undef, 4 * (ch.q + ch.V))
-    check(ccall((:bnr_chain_rhat_stats, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Cdouble}), ch.h, first_row, nsamp, out))
-    out
+# Summary statistics on the device (gibbs.jl:1214-1250): (mean γ, lower, upper, P(ξ=1)); ranks are 1-based positions in the sorted sample
+function summary_stats(ch::Chain, nburn, nsamp; interval=95)
+    lb = (100 - interval) / 200
+    klo, khi = Int(round(nsamp * lb)), Int(round(nsamp * (1 - lb)))
+    m, lo, hi, p = zeros(ch.q), zeros(ch.q), zeros(ch.q), zeros(ch.V)
+    check(ccall((:bnr_chain_summary, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+        ch.h, nburn + 1, nsamp, klo, khi, m, lo, hi, p))
+    m, lo, hi, p
 end
 
-function rhat_from_stats(stats::Matrix{Float64}, nsamp)          # columns = chains
-    np = size(stats, 1) ÷ 4
-    out = Vector{Float64}(undef, np)
-    check(ccall((:bnr_rhat_from_stats, LIB), Cint, (Ptr{Cdouble}, Int32, Int32, Int32, Ptr{Cdouble}), stats, size(stats, 2), np, nsamp, out))
-    out
+# ---- the ranks of a fit (bnr_comm): nothing (one process), or the library's RCCL communicator.  Rank 0 calls `unique_id()`, the
+# 128 bytes travel to the other workers by whatever connects them (e.g. `remotecall_fetch`), then EVERY rank calls `rccl_comm`.
+struct Comm
+    h::Ptr{Cvoid}; rank::Int; world::Int
+end
+function unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:bnr_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id))
+    id
+end
+function rccl_comm(id::Vector{UInt8}, rank, world, device)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:bnr_comm_create_rccl, LIB), Cint, (Ptr{UInt8}, Int32, Int32, Int32, Ref{Ptr{Cvoid}}), id, rank, world, device, out))
+    Comm(out[], rank, world)
+end
+close(c::Comm) = ccall((:bnr_comm_destroy, LIB), Cint, (Ptr{Cvoid},), c.h)
+
+# return_psrf_VOI (gibbs.jl:771-789) over ALL chains of the fit, wherever they live: (rhatξ, rhatγ)
+function psrf(chains::Vector{Chain}, num_chains, comm::Union{Comm,Nothing}, burn, nsamp, V, q)
+    hs = Ptr{Cvoid}[ch.h for ch in chains]
+    rx, rg = zeros(V), zeros(q)
+    GC.@preserve hs check(ccall((:bnr_rhat, LIB), Cint, (Ptr{Ptr{Cvoid}}, Int32, Int32, Ptr{Cvoid}, Int32, Int32, Ptr{Cdouble}, Ptr{Cdouble}),
+        hs, length(hs), num_chains, comm === nothing ? C_NULL : comm.h, burn, nsamp, rx, rg))
+    rx, rg
 end
 
-# generate_samples!(X, y, R; ...) (gibbs.jl:897-1020), single round; the PSRF top-up loop is the reference's own code
-# with `initialize_and_run!`/`run!`/`copy_table!` replaced by Chain/run!/bnr_chain_move_rows.
-function generate_samples!(X, y, R; η=1.01, ζ=1.0, ι=1.0, aΔ=1.0, bΔ=1.0, ν=10, nburn=30000, nsamp=20000,
-                           x_transform=true, num_chains=2, seed=nothing, purge_burn=nothing, device=0)
+# generate_samples!(X, y, R; ...) (gibbs.jl:897-1020).  `seed` must be the same on every rank (the reference draws it once, :928).
+function generate_samples!(X, y, R; η=1.01, ζ=1.0, ι=1.0, aΔ=1.0, bΔ=1.0, ν=10, nburn=30000, nsamp=20000, maxburn=50000,
+                           psrf_cutoff=1.2, x_transform=true, suppress_timer=false, num_chains=2, seed=nothing, purge_burn=nothing,
+                           device=0, comm::Union{Comm,Nothing}=nothing, tick=nothing)
     V = x_transform ? size(X[1], 1) : Int64((-1 + sqrt(1 + 8 * size(X, 2))) / 2)
     q = floor(Int, V * (V + 1) / 2)
-    X_new = Matrix{Float64}(undef, size(X, 1), q)
-    setup_X!(X_new, X, x_transform)
     total = nburn + nsamp
+    prog_freq = 1000 >= nburn ? 10 : 1000                                        # :923-926
+    if !isnothing(purge_burn) && (purge_burn < nburn) && purge_burn != 0         # :930-936
+        if nburn % purge_burn != 0
+            purge_burn = purge_burn - (nburn % purge_burn)
+        end
+    else
+        purge_burn = nothing
+    end
     tot_save = isnothing(purge_burn) ? total : nsamp + purge_burn
     seed = isnothing(seed) ? rand(1:55555) : seed
-    chains = [Chain(X_new, Vector{Float64}(y), R, tot_save, seed, c; η, ζ, ι, aΔ, bΔ, ν, device) for c in 1:num_chains]
-    for ch in chains
-        init_prior!(ch)
-        run!(ch, 2, nburn, total, purge_burn)
+    rank, world = comm === nothing ? (0, 1) : (comm.rank, comm.world)
+    ids = [c for c in 1:num_chains if (c - 1) % world == rank]                   # pmap's round-robin over workers
+    yv = Vector{Float64}(y)
+    chains = Chain[]
+    for c in ids
+        push!(chains, isempty(chains) ? Chain(X, yv, R, tot_save, seed, c; x_transform, η, ζ, ι, aΔ, bΔ, ν, device) :
+                                        chain_like(chains[1], seed, c, tot_save))
     end
+    foreach(init_prior!, chains)
+    runner = length(chains) > 1 ? Group(chains) : (isempty(chains) ? nothing : chains[1])
+    isnothing(runner) || run!(runner, 2, nburn, total, purge_burn; prog_freq, tick = 1 in ids ? tick : nothing)
+    tot_generated = nburn + nsamp
     stt = isnothing(purge_burn) ? nburn : purge_burn
-    stats = hcat([rhat_stats(ch, stt + 1, nsamp) for ch in chains]...)
-    r = rhat_from_stats(stats, nsamp)
-    state = fetch!(new_table(tot_save, V, R), chains[1])
-    Results(state, Table(ξ = r[q+1:end]), Table(γ = r[1:q]), stt, nsamp)
+    rx, rg = psrf(chains, num_chains, comm, stt, nsamp, V, q)
+    println(stderr, tot_generated, " samples generated. Max PSRF XI: ", round(maximum(rx), digits=2), ". Max PSRF Gamma: ", round(maximum(rg), digits=2))
+    while (maximum(rx) > psrf_cutoff || maximum(rg) > psrf_cutoff) && tot_generated < (maxburn + nsamp)
+        num2move = !isnothing(purge_burn) ? (nsamp + purge_burn <= nburn ? 1 : nsamp + purge_burn - nburn) : total - nburn   # :963-974
+        tot_sze = tot_save
+        for ch in chains                                                         # copy_table! loop :991-993
+            move_rows!(ch, 1, tot_sze - num2move + 1, num2move)
+        end
+        last = num2move > 1 ? num2move + nburn : nburn                           # run! :997-999
+        isnothing(runner) || run!(runner, num2move + 1, nburn > nsamp ? nburn - nsamp + num2move : 0, last, purge_burn;
+                                  prog_freq, tick = 1 in ids ? tick : nothing)
+        tot_generated = tot_generated + last - num2move
+        rx, rg = psrf(chains, num_chains, comm, stt, nsamp, V, q)
+        println(stderr, tot_generated, " samples generated. Max PSRF XI: ", round(maximum(rx), digits=3), ". Max PSRF Gamma: ", round(maximum(rg), digits=3))
+    end
+    state = 1 in ids ? fetch!(new_table(tot_save, V, R), chains[1]) : nothing    # only chain 1's trace is returned (gibbs.jl:788)
+    Results(state, Table(ξ = rx), Table(γ = rg), stt, nsamp)
 end
 
 end # module

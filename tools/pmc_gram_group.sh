@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC counters of k_gram, one chain and a lockstep group of 8, separate --pmc passes (guide: FETCH_SIZE/WRITE_SIZE in KB,
-# FETCH_SIZE doubled on gfx950).  Writes gpurun_out/gram_pmc_round1b.json.  Runs on the GPU box.
+# FETCH_SIZE doubled on gfx950).  Writes gpurun_out/gram_pmc_round2.json.  Runs on the GPU box.
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 cat > /tmp/tg.py <<PY
@@ -47,6 +47,6 @@ for who in d:
     if "WRITE_SIZE" in c: o["write_bytes_per_launch"] = c["WRITE_SIZE"] * 1024
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c: o["traffic_bytes_per_launch"] = o["fetch_bytes_per_launch"] + o["write_bytes_per_launch"]
     out[who] = o
-json.dump(out, open("$R/gpurun_out/gram_pmc_round1b.json", "w"), indent=1)
+json.dump(out, open("$R/gpurun_out/gram_pmc_round2.json", "w"), indent=1)
 print(json.dumps(out)[:600])
 PY
