@@ -144,7 +144,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: never depend on what the box's hostname resolves to
+            # one node: neither the rendezvous (gloo) nor RCCL's bootstrap socket may depend on what the box's hostname or its
+            # outward interface resolve to; the data path of RCCL stays xGMI / shared memory whatever carries the bootstrap
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         with _StdoutToStderr():                                 # RCCL prints a banner on stdout when a communicator comes up
             dist.init_process_group("gloo", rank=rank, world_size=world)
             if one_dev:
