@@ -225,9 +225,9 @@ class Chain:
         return self
 
     def close(self):
-        if getattr(self, "h", None) and self.h.value:
-            self.L.bnr_chain_destroy(self.h)
-            self.h = C.c_void_p()
+        h, self.h = getattr(self, "h", None), None          # (no ctypes call when the interpreter is shutting down: C may be gone)
+        if h and h.value and getattr(self, "L", None) is not None:
+            self.L.bnr_chain_destroy(h)
 
     __del__ = close
 
@@ -361,9 +361,9 @@ class Group:
         check(self.L.bnr_group_create(arr, len(self.chains), C.byref(self.h)))
 
     def close(self):
-        if getattr(self, "h", None) and self.h.value:
-            self.L.bnr_group_destroy(self.h)
-            self.h = C.c_void_p()
+        h, self.h = getattr(self, "h", None), None
+        if h and h.value and getattr(self, "L", None) is not None:
+            self.L.bnr_group_destroy(h)
 
     __del__ = close
 
@@ -436,9 +436,9 @@ class Comm:
         return out.reshape(self.world, s.size)
 
     def close(self):
-        if getattr(self, "h", None) and self.h.value:
-            self.L.bnr_comm_destroy(self.h)
-            self.h = C.c_void_p()
+        h, self.h = getattr(self, "h", None), None
+        if h and h.value and getattr(self, "L", None) is not None:
+            self.L.bnr_comm_destroy(h)
 
     __del__ = close
 
