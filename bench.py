@@ -154,10 +154,28 @@ def main():
                 comm = bnr_amd.make_comm(device=local_rank, force=True)
                 exchange = "bnr_rhat: host-callback communicator over gloo (one-device rehearsal)"
             else:
-                box = [bnr_amd.Comm.unique_id() if rank == 0 else None]
+                import torch
+                why = ""
+                try:
+                    box = [bnr_amd.Comm.unique_id() if rank == 0 else None]
+                except bnr_amd.BnrError as e:                   # librccl missing on rank 0: every rank must learn it
+                    box, why = [None], str(e)
                 dist.broadcast_object_list(box, src=0)
-                comm = bnr_amd.Comm.rccl(box[0], rank, world, local_rank)
-                exchange = "bnr_rhat: ncclAllGather on the library's RCCL communicator (rendezvous: torch.distributed/gloo)"
+                if box[0] is not None:
+                    try:
+                        comm = bnr_amd.Comm.rccl(box[0], rank, world, local_rank)
+                    except bnr_amd.BnrError as e:
+                        why = str(e)
+                # all ranks use the same transport: RCCL only if it came up everywhere (agreed over gloo)
+                ok = torch.tensor([1 if comm is not None else 0])
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 1:
+                    exchange = "bnr_rhat: ncclAllGather on the library's RCCL communicator (rendezvous: torch.distributed/gloo)"
+                else:
+                    if comm is not None:
+                        comm.close()
+                    comm = bnr_amd.make_comm(device=local_rank, force=True)
+                    exchange = "bnr_rhat: host-callback communicator over gloo (the RCCL communicator did not come up on every rank%s)" % (": " + why if why else "")
             comm.allgather(np.zeros(8))                         # brings the channels up now, not in the timed region
             dist.barrier()
 
