@@ -575,6 +575,114 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
     BNR_GSTAMP(3);
 }
 
+// k_gram8: the same Gram, the same task map, the same summation order per element (bitwise the same partial tiles) -- for
+// EIGHT wavefronts per SIMD.  The issue rate of v_mfma_f64_16x16x4_f64 on a SIMD depends on how many waves feed it, not on how
+// many independent accumulators a wave has (profiles/round1_mfma_f64_peak.txt: 1 wave 139-180 cycles per MFMA whatever NACC,
+// 2 waves 103, 4 waves 92, 8 waves 71; 64 = spec).  Eight waves per SIMD = four 512-thread workgroups per CU: at most 64 VGPRs per
+// wave and 40 KiB of LDS per workgroup.  Hence batches of 8 columns (half the staging registers and half the LDS image of k_gram's
+// 16: 2 K-groups x 2 buffers x [I | J] x 8 x 64 doubles = 32 KiB; a barrier per 8 MFMAs of a wave) and a K-group reduction that needs
+// one tile of LDS instead of two (K-group 1 parks its tile, K-group 0 adds its registers and stores).
+template <class SRC>
+__global__ __launch_bounds__(512, 6) void k_gram8(const SRC chain_src, int s, int nchains)
+{
+    constexpr int KG = 2, KB = 8;
+    const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
+    const int gchain = gr % nchains, gslot = (gr / nchains) * 8 + gx;
+    const bnr_dev &cd = chain_src.at(gchain);
+    __shared__ double sred[BNR_GT * BNR_GT];          // 32 KiB: staging buffers during the loop, then K-group 1's tile
+    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
+    const double *Sp = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
+    if (gslot >= cd.ksplit * (cd.ntile * (cd.ntile + 1) / 2)) return;
+    const int task = cd.gmap[gslot];
+    int t = task & 0xFFFF, ti = 0;
+    const int ks = task >> 16;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    int tj = t - ti * (ti + 1) / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kg = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
+    const int kchunk = cd.q_pad / cd.ksplit;          // multiple of 8 KG (host guarantees)
+    const int ksub = kchunk / KG;                     // multiple of 8
+    const int eb = ks * kchunk + kg * ksub;
+    const int nbatch = ksub / KB;
+    const size_t ld = cd.n_pad;
+    const int li = lane & 15, lk = lane >> 4;
+    // staging: this thread moves rows (2 rp, 2 rp + 1) of column c of both panels
+    const int tg = threadIdx.x & 255, c = tg >> 5, rp = tg & 31;
+    // per-lane offsets inside a batch are small (8 columns): 32-bit, so that the loads use the scalar-base + 32-bit-offset form
+    const unsigned offI = (unsigned)(ti * BNR_GT + 2 * rp) + (unsigned)c * (unsigned)ld, offJ = (unsigned)(tj * BNR_GT + 2 * rp) + (unsigned)c * (unsigned)ld;
+    const double *xb = cd.X + (size_t)eb * ld;
+    const double *sb = Sp + eb;
+    const int smax = cd.q - 1 - eb;
+    constexpr int PANEL = KB * BNR_GT;                 // doubles per panel (8 columns x 64 rows)
+    double *stg = sred + (size_t)kg * (4 * PANEL);     // [buf][I|J][col][row ^ swizzle]
+    const int woff = c * BNR_GT + ((2 * rp) ^ ((c & 1) << 4));
+    const int sw = (lk & 1) << 4;
+    const int ra0 = (wj * 32 + li) ^ sw, ra1 = (wj * 32 + 16 + li) ^ sw, rb0 = (wi * 32 + li) ^ sw, rb1 = (wi * 32 + 16 + li) ^ sw;
+    bnr_d4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};   // c[jt][it]
+    bnr_d2 ri, rj;
+    double sv;
+#define BNR_G8_LOAD(BIDX)                                                                    \
+    do {                                                                                      \
+        const double *cb_ = xb + (size_t)(BIDX) * (KB * ld);                                  \
+        const int si_ = (BIDX) * KB + c;                                                      \
+        sv = sb[si_ < smax ? si_ : smax];                                                     \
+        ri = *(const bnr_d2 *)(cb_ + offI);                                                   \
+        rj = *(const bnr_d2 *)(cb_ + offJ);                                                   \
+    } while (0)
+#define BNR_G8_STORE(BUF)                                                                     \
+    do {                                                                                      \
+        double *nx_ = stg + (size_t)(BUF) * (2 * PANEL);                                      \
+        *(bnr_d2 *)(nx_ + woff) = ri * sv;                                                    \
+        *(bnr_d2 *)(nx_ + PANEL + woff) = rj;                                                 \
+    } while (0)
+#define BNR_G8_COMPUTE(BUF, K2)                                                               \
+    do {                                                                                      \
+        const double *bufI = stg + (size_t)(BUF) * (2 * PANEL), *bufJ = bufI + PANEL;         \
+        const int kk = (4 * (K2) + lk) * BNR_GT;                                              \
+        double a0 = bufJ[kk + ra0], a1 = bufJ[kk + ra1];                                      \
+        double b0 = bufI[kk + rb0], b1 = bufI[kk + rb1];                                      \
+        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);                     \
+        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);                     \
+        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);                     \
+        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);                     \
+    } while (0)
+    // batches past the end of the slice read the following columns or the zero-padded tail of X (q_pad + 64 columns are
+    // allocated); they are stored but never used by a compute step
+    BNR_G8_LOAD(0);
+    BNR_G8_STORE(0);
+    BNR_G8_LOAD(1);
+    __syncthreads();
+    for (int b = 0; b < nbatch; ++b) {
+        BNR_G8_COMPUTE(b & 1, 0);
+        BNR_G8_STORE((b + 1) & 1);                 // batch b+1; its buffer was released by the last barrier
+        BNR_G8_LOAD(b + 2);
+        BNR_G8_COMPUTE(b & 1, 1);
+        __syncthreads();
+    }
+    // tile element (i,j) lives at [j*64 + i]; this lane: j = wj*32 + jt*16 + (lane>>4) + 4 r, i = wi*32 + it*16 + (lane&15)
+    const int jb = wj * 32 + (lane >> 4), ib = wi * 32 + (lane & 15);
+    if (kg == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sred[(jb + 4 * r) * BNR_GT + ib] = c00[r];
+            sred[(jb + 4 * r) * BNR_GT + ib + 16] = c01[r];
+            sred[(jb + 16 + 4 * r) * BNR_GT + ib] = c10[r];
+            sred[(jb + 16 + 4 * r) * BNR_GT + ib + 16] = c11[r];
+        }
+    }
+    __syncthreads();
+    if (kg == 0) {
+        double *out = cd.Gpart + ((size_t)ks * (cd.ntile * (cd.ntile + 1) / 2) + t) * (BNR_GT * BNR_GT);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            out[(jb + 4 * r) * BNR_GT + ib] = c00[r] + sred[(jb + 4 * r) * BNR_GT + ib];
+            out[(jb + 4 * r) * BNR_GT + ib + 16] = c01[r] + sred[(jb + 4 * r) * BNR_GT + ib + 16];
+            out[(jb + 16 + 4 * r) * BNR_GT + ib] = c10[r] + sred[(jb + 16 + 4 * r) * BNR_GT + ib];
+            out[(jb + 16 + 4 * r) * BNR_GT + ib + 16] = c11[r] + sred[(jb + 16 + 4 * r) * BNR_GT + ib + 16];
+        }
+    }
+}
+
 // E = extended matrix of the factorization, (2 n_pad + 32) x n_pad, column-major, leading dimension ldE:
 //     rows [0, n_pad)            G + I  (lower triangle)                      -> L
 //     rows [n_pad, 2 n_pad)      Y = I                                        -> L^-T   (back substitution becomes a GEMV)

@@ -306,7 +306,7 @@ def main():
                                       "literal layout, ONE chain per GPU = %d chains on %d GPUs, is the single_chain record of this line)" % (C, world, world)),
                        "chains_per_gpu": C, "seed": a.seed},
             "timed_region": {"sweeps_replayed_from_graphs": int(replayed_sweeps), "sweeps_launched_eagerly": int(eager_sweeps)},
-            "roofline": {"bound": "mfma", "kernel": "k_gram (X diag(S) X', v_mfma_f64_16x16x4_f64)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "k_gram8 / k_gram (X diag(S) X', v_mfma_f64_16x16x4_f64)", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": "profiles/round2_gram_pmc.json (FETCH_SIZE x2 + WRITE_SIZE of a launch of this shape, separate --pmc passes, tools/pmc_gram_group.sh)",
                          "sweep_frac": sweep_tflops / FP64_MFMA_PEAK_TFLOPS, "sweep_achieved": sweep_tflops, "sweep_flops_per_chain_iteration": f_iter,

@@ -26,7 +26,7 @@ agg = collections.defaultdict(list)
 for f in glob.glob("/tmp/pm_$tag/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_gram<" in k:
+        if "k_gram" in k and "reduce" not in k:
             agg[("one" if "bnr_one" in k else "group8", r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (who, c), v in sorted(agg.items()):
     print(who, c, sum(v) / len(v), len(v))
