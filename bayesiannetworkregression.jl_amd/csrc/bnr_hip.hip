@@ -539,11 +539,11 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
     } else {
         // Two kernels, the same partial tiles bit for bit (same K split, K-groups and accumulation order): k_gram8 (8-column batches,
         // three workgroups = 6 waves per SIMD) feeds the f64 MFMA pipe from more waves and leaves room on the CU for the scalar
-        // branch beside it (8 chains: 205 vs 211 us alone, 222 vs 267 us beside the scalar branch); k_gram (16-column batches, two
-        // workgroups per CU, half the barriers) stays ahead only for ONE chain whose launch is a single round of long K slices
-        // (n=500, V=300: 228 vs 237 us).
+        // branch beside it (8 chains: 205 vs 211 us alone, 221 vs 267 us beside the scalar branch) -- when the launch has more
+        // workgroups than two per CU.  A launch that fits in one round (one chain: 252 workgroups at the headline size) never reaches
+        // that occupancy and is better off with k_gram's 16-column batches = half the barriers (33.5 vs 36.0 us; n=500, V=300: 228 vs 237).
         static const int forced = getenv("BNR_GRAM_VARIANT") ? atoi(getenv("BNR_GRAM_VARIANT")) : 0;      // 8 / 16: experiments
-        const bool wide = forced ? forced == 16 : (x.nb == 1 && d.q_pad / d.ksplit >= 2048 && ntl * d.ksplit <= 2 * x.ncu);
+        const bool wide = forced ? forced == 16 : ((long)x.nb * ntl * d.ksplit <= 2L * x.ncu);
         if (!wide) {
             if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8<bnr_one>), ggrid, dim3(512), 0, st, bnr_one{d}, s, 1);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8<bnr_many>), ggrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb);
