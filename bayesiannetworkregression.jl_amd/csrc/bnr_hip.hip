@@ -37,6 +37,7 @@ struct bnr_exec {
     std::vector<hipEvent_t> fj;                         // fork/join events
     size_t fj_next = 0;
     int overlap = 1;
+    int gram_variant = 0;                               // 0: chosen per launch; 8 / 16: k_gram8 / k_gram forced (tests, experiments)
     int use_graph = 1, graph_k = 8;
     struct rung { int k; hipGraph_t graph; hipGraphExec_t gexec; };
     std::vector<rung> ladder;                           // captured graphs of graph_k, graph_k/2, ..., 1 sweeps: any batch is replayed
@@ -542,8 +543,7 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
         // branch beside it (8 chains: 205 vs 211 us alone, 221 vs 267 us beside the scalar branch) -- when the launch has more
         // workgroups than two per CU.  A launch that fits in one round (one chain: 252 workgroups at the headline size) never reaches
         // that occupancy and is better off with k_gram's 16-column batches = half the barriers (33.5 vs 36.0 us; n=500, V=300: 228 vs 237).
-        static const int forced = getenv("BNR_GRAM_VARIANT") ? atoi(getenv("BNR_GRAM_VARIANT")) : 0;      // 8 / 16: experiments
-        const bool wide = forced ? forced == 16 : ((long)x.nb * ntl * d.ksplit <= 2L * x.ncu);
+        const bool wide = x.gram_variant ? x.gram_variant == 16 : ((long)x.nb * ntl * d.ksplit <= 2L * x.ncu);
         if (!wide) {
             if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8<bnr_one>), ggrid, dim3(512), 0, st, bnr_one{d}, s, 1);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8<bnr_many>), ggrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb);
@@ -938,6 +938,10 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
 {
     if (!strcmp(name, "graph")) { x.use_graph = (int)value; return BNR_OK; }
     if (!strcmp(name, "overlap")) { x.overlap = (int)value; drop_graph(x); return BNR_OK; }
+    if (!strcmp(name, "gram_variant")) {
+        if (value != 0 && value != 8 && value != 16) return fail(BNR_ERR_BAD_ARG, "gram_variant must be 0 (auto), 8 or 16");
+        x.gram_variant = (int)value; drop_graph(x); return BNR_OK;
+    }
     if (!strcmp(name, "graph_k")) { if (value < 1 || value > 256) return fail(BNR_ERR_BAD_ARG, "graph_k out of range"); x.graph_k = (int)value; drop_graph(x); return BNR_OK; }
     if (!strcmp(name, "profiling")) { if (x.profiling != (int)value) drop_graph(x); x.profiling = (int)value; return BNR_OK; }
     return fail(BNR_ERR_BAD_ARG, std::string("unknown option ") + name);

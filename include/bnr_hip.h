@@ -226,6 +226,8 @@ int bnr_chain_debug_copy(bnr_chain *chain, int32_t which, double *out, int64_t c
  *   "graph"     1 (default): replay captured hipGraphs of graph_k sweeps; 0: launch every kernel eagerly
  *   "graph_k"   sweeps per captured graph (default 8)
  *   "overlap"   1 (default): scalar branch and Gram/factorization branch of a sweep on two streams; 0: one stream
+ *   "gram_variant" 0 (default): the Gram kernel is chosen per launch (k_gram8 when the launch has more than two workgroups per CU,
+ *               k_gram otherwise); 8 / 16 force one of them.  Both write the same partial tiles bit for bit.
  *   "profiling" 1: record HIP events around every k_gram launch (forces eager launches), see bnr_chain_last_timing */
 int bnr_chain_set_option(bnr_chain *chain, const char *name, int64_t value);
 

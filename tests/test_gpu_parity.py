@@ -924,6 +924,37 @@ def test_rhat_through_the_library_communicator(gpu, test1):
         c.close()
 
 
+def test_gram_kernels_write_the_same_tiles(gpu):
+    """k_gram (16-column batches, two workgroups per CU) and k_gram8 (8-column batches, three per CU) are chosen per launch by
+    its size; both follow the same K split, K-groups and accumulation order, so a chain's table must not depend on the choice:
+    bitwise equal over ragged and tiny shapes (n not a multiple of 64, V = 2, q below one batch, R > V), alone and in a group."""
+    shapes = [(40, 8, 3), (1, 2, 1), (3, 2, 4), (65, 5, 2), (129, 12, 7), (200, 50, 5), (64, 33, 10), (500, 100, 7)]
+    for n, V, R in shapes:
+        X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=77 + n)
+        tabs = {}
+        for variant in (16, 8):
+            ch = bnr_amd.Chain(X, y, R, 6, 3, 1)
+            mates = [bnr_amd.Chain.like(ch, 3, c, 6) for c in (2, 3)]
+            for c in [ch] + mates:
+                c.init_prior()
+            g = bnr_amd.Group([mates[0], ch, mates[1]])
+            g.set_option("gram_variant", variant)
+            g.run(2, 6, 6)
+            solo = bnr_amd.Chain.like(ch, 3, 1, 6)
+            solo.set_option("gram_variant", variant)
+            solo.init_prior()
+            solo.run(2, 6, 6)
+            tabs[variant] = (ch.fetch(), solo.fetch())
+            assert ch.counters()["chol_fail"] == 0
+            g.close()
+            for c in [ch, solo] + mates:
+                c.close()
+        for k in bo.COLUMNS:
+            assert np.array_equal(tabs[16][0][k], tabs[8][0][k]), ("group", n, V, R, k)
+            assert np.array_equal(tabs[16][1][k], tabs[8][1][k]), ("alone", n, V, R, k)
+            assert np.array_equal(tabs[16][0][k], tabs[16][1][k]), ("group vs alone", n, V, R, k)
+
+
 def test_prepare_never_changes_results(gpu, test1):
     """bnr_chain_prepare / bnr_group_prepare capture the graphs and replay them once on scratch rows: tables, iteration
     counters and event counters of a chain alone and of a lockstep group are bitwise what they are without it -- called
