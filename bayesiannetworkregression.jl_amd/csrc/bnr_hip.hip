@@ -34,10 +34,16 @@ struct bnr_exec {
     bnr_dev *cds = nullptr;                             // device array of nb structs
     const bnr_dev *shape = nullptr;                     // host struct of member 0 (sizes are equal for all members)
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: the Gram branch of a sweep
+    hipStream_t stream3 = nullptr, stream4 = nullptr;  // pipelined schedule: the factorization beside the Gram; the sacrificial first branch
+    int pipeline = -1;                                  // -1: chosen by size / availability; 0: the factorization follows the Gram; 1: beside it
+    int gate_us = 3000;                                 // how long a gate of the factorization polls for the Gram's progress
+    unsigned *gctl = nullptr;                           // k_gram8p: queue heads and tickets
+    const unsigned *resv = nullptr;                     // reserved compute units (device table shared per device), nullptr: none
     std::vector<hipEvent_t> fj;                         // fork/join events
     size_t fj_next = 0;
     int overlap = 1;
     int gram_variant = 0;                               // 0: chosen per launch; 8 / 16: k_gram8 / k_gram forced (tests, experiments)
+    int factor_variant = -1;                            // -1: chosen by size; 0: right-looking k_chol_step (+ k_gram_reduce); 1: left-looking k_chol_ll
     int use_graph = 1, graph_k = 8;
     struct rung { int k; hipGraph_t graph; hipGraphExec_t gexec; };
     std::vector<rung> ladder;                           // captured graphs of graph_k, graph_k/2, ..., 1 sweeps: any batch is replayed
@@ -110,7 +116,9 @@ static int ensure_lds_attributes(int device)
     if (done[device]) return BNR_OK;
     const int big = 124 * 1024;
     const void *fns[] = {(const void *)&k_tail<bnr_one>, (const void *)&k_tail<bnr_many>, (const void *)&k_backproj<bnr_one>,
-                         (const void *)&k_backproj<bnr_many>, (const void *)&k_solve_a4<bnr_one>, (const void *)&k_solve_a4<bnr_many>};
+                         (const void *)&k_backproj<bnr_many>, (const void *)&k_solve_a4<bnr_one>, (const void *)&k_solve_a4<bnr_many>,
+                         (const void *)&k_chol_ll<bnr_one>, (const void *)&k_chol_ll<bnr_many>,
+                         (const void *)&k_gram_gate<bnr_one>, (const void *)&k_gram_gate<bnr_many>};
     for (const void *f : fns) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     done[device] = 1;
     return BNR_OK;
@@ -303,11 +311,11 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     TRY(exec_init(c->x, device, 1, &c->d));
     if (donor) {
         c->in = donor->in;
-        d.X = donor->d.X; d.y = donor->d.y; d.ek = donor->d.ek; d.el = donor->d.el; d.gmap = donor->d.gmap;
+        d.X = donor->d.X; d.y = donor->d.y; d.ek = donor->d.ek; d.el = donor->d.el; d.gmap = donor->d.gmap; d.gmapc = donor->d.gmapc;
     } else {
         c->in = std::make_shared<bnr_inputs>();
         double *Xd = nullptr, *yd = nullptr;
-        int *ek = nullptr, *el = nullptr, *gm = nullptr;
+        int *ek = nullptr, *el = nullptr, *gm = nullptr, *gmc = nullptr;
         auto in_alloc = [&](void **ptr, size_t bytes) -> int {
             HIPCHK(hipMalloc(ptr, std::max<size_t>(bytes, 8)));
             c->in->bufs.push_back(*ptr);
@@ -350,8 +358,16 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
             }
             TRY(in_alloc((void **)&gm, sizeof(int) * ntask));
             hipMemcpy(gm, map.data(), ntask * sizeof(int), hipMemcpyHostToDevice);
+            // k_gram8p: eight queues (K slices ks = x mod 8 on XCD x), each in tile-COLUMN order; offsets: gram_queues()
+            std::vector<int> mapc;
+            for (int x = 0; x < 8; ++x)
+                for (int tc = 0; tc < d.ntile; ++tc)
+                    for (int ti = tc; ti < d.ntile; ++ti)
+                        for (int ks = x; ks < d.ksplit; ks += 8) mapc.push_back((ti * (ti + 1) / 2 + tc) | (ks << 16));
+            TRY(in_alloc((void **)&gmc, sizeof(int) * ntask));
+            hipMemcpy(gmc, mapc.data(), ntask * sizeof(int), hipMemcpyHostToDevice);
         }
-        d.X = Xd; d.y = yd; d.ek = ek; d.el = el; d.gmap = gm;
+        d.X = Xd; d.y = yd; d.ek = ek; d.el = el; d.gmap = gm; d.gmapc = gmc;
     }
     TRY(alloc_trace(c, tot_save, &d.trace));
     TRY(dev_alloc(c, &d.Wbuf, d.q_pad));
@@ -373,6 +389,7 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     TRY(dev_alloc(c, &d.Psum, (size_t)d.nblk_bp * (1 + 3 * R)));
     TRY(dev_alloc(c, &d.counters, 16));
     TRY(dev_alloc(c, &d.stamp, 8 * ntl));
+    TRY(dev_alloc(c, &d.gprog, d.ntile + 4));
     TRY(dev_alloc(c, &d.dbg, 1024));
     c->plan_cap = 1 << 16;
     TRY(dev_alloc(c, &c->plan_dev, c->plan_cap));
@@ -407,6 +424,49 @@ int bnr_chain_create_like(const bnr_chain *donor, uint64_t seed, int32_t chain_i
     return chain_build(donor, a.n, a.V, a.R, x_source(), nullptr, &h, seed, chain_id, donor->device, tot_save, out);
 }
 
+// Compute units the persistent Gram keeps off (k_gram8p): the `per_se` highest cu ids of EVERY shader engine -- the dispatcher walks
+// the shader engines round-robin and a workgroup whose SE has no room blocks every workgroup behind it, so all SEs must offer
+// the same room.  Which cu ids exist differs per SE (8 of 9 are active): measured once per device by k_cu_census.  Returns a
+// device table [XCD * 4 + SE] -> bit mask of reserved cu ids, or nullptr when the census does not look like 8 XCDs x 4 SEs x 8 CUs.
+static const unsigned *reserved_cus(int device, int per_se)
+{
+    static std::mutex mu;
+    static std::vector<unsigned *> tab;
+    static std::vector<char> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if ((int)done.size() <= device) { done.resize(device + 1, 0); tab.resize(device + 1, nullptr); }
+    if (done[device]) return tab[device];
+    done[device] = 1;
+    const char *off = getenv("BNR_NO_RESERVED_CUS");
+    if (off && atoi(off)) return nullptr;
+    unsigned *d = nullptr, h[33];
+    if (hipMalloc((void **)&d, sizeof h) != hipSuccess) return nullptr;
+    bool ok = hipMemset(d, 0, sizeof h) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_cu_census, dim3(4096), dim3(1024), 0, nullptr, d, 2000);     // 20 us each, 1024 threads: one or two per CU at a time
+        ok = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    int total = 0;
+    for (int i = 0; ok && i < 32; ++i) {
+        const int n = __builtin_popcount(h[i]);
+        total += n;
+        if (n < 2 * per_se + 2) ok = false;                                              // an SE this small: do not reserve anything
+    }
+    hipDeviceProp_t prop;
+    if (ok && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount != total) ok = false;
+    if (ok) {
+        for (int i = 0; i < 32; ++i) {
+            unsigned m = 0, left = h[i];
+            for (int k = 0; k < per_se; ++k) { const unsigned top = 31u - (unsigned)__builtin_clz(left); m |= 1u << top; left &= ~(1u << top); }
+            h[i] = m;
+        }
+        ok = hipMemcpy(d, h, 32 * sizeof(unsigned), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) { hipFree(d); return nullptr; }
+    tab[device] = d;
+    return d;
+}
+
 static void drop_graph(bnr_exec &x)
 {
     for (auto &r : x.ladder) { if (r.gexec) hipGraphExecDestroy(r.gexec); if (r.graph) hipGraphDestroy(r.graph); }
@@ -421,6 +481,11 @@ static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape)
     }
     HIPCHK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&x.stream2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&x.stream3, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&x.stream4, hipStreamNonBlocking));
+    HIPCHK(hipMalloc((void **)&x.gctl, 64));
+    HIPCHK(hipMemset(x.gctl, 0, 64));
+    x.resv = reserved_cus(device, 1);
     HIPCHK(hipMalloc((void **)&x.cds, sizeof(bnr_dev) * nb));
     HIPCHK(hipHostMalloc((void **)&x.cds_pin, sizeof(bnr_dev) * nb));
     HIPCHK(hipMalloc((void **)&x.status_dev, sizeof(long long) * 16 * nb));
@@ -431,6 +496,9 @@ static void exec_free(bnr_exec &x)
 {
     if (x.stream) { hipStreamSynchronize(x.stream); }
     if (x.stream2) { hipStreamSynchronize(x.stream2); }
+    if (x.stream3) { hipStreamSynchronize(x.stream3); hipStreamDestroy(x.stream3); }
+    if (x.stream4) { hipStreamSynchronize(x.stream4); hipStreamDestroy(x.stream4); }
+    if (x.gctl) hipFree(x.gctl);
     drop_graph(x);
     if (x.stream) hipStreamDestroy(x.stream);
     if (x.stream2) hipStreamDestroy(x.stream2);
@@ -517,6 +585,28 @@ static void launch_node(bnr_exec &x, int s, int mode)
 { BNR_LAUNCH(k_node, dim3(x.shape->V, 1, x.nb), dim3(64), 64 * (2 * x.shape->R + 1) * sizeof(double), x.stream, x, s, mode); }
 static void launch_xpass(bnr_exec &x, int s, int which)
 { BNR_LAUNCH(k_xpass, dim3(round_up(x.shape->nblk_x, 8) * x.nb), dim3(256), 3 * x.shape->chunk_x * sizeof(double), x.stream, x, s, which, x.nb); }
+// Which factorization: right-looking (k_chol_step behind k_gram_reduce: the trailing update spread over the whole chip) unless the
+// caller asks for the left-looking one (k_chol_ll: no reduction pass, ceil(nbk/4) + nbk - 1 workgroups per chain and launch, can
+// run beside the Gram).  Same tables bit for bit.
+static bool left_looking(const bnr_exec &x)
+{
+    return x.factor_variant == 1;                        // opt-in: measured slower than right-looking in every schedule tried (notes round 3, B)
+}
+// The sweep's schedule: pipelined (option "pipeline" = 1) = the factorization runs BESIDE the Gram (k_gram8p keeps off the reserved
+// CUs, k_chol_ll's gates follow its progress column by column); otherwise it follows the Gram on the same stream.
+static bool pipelined(const bnr_exec &x)
+{
+    if (!left_looking(x) || !x.overlap || !x.resv || x.shape->gram_kg != 2) return false;
+    return x.pipeline == 1;                              // opt-in (notes round 3, B)
+}
+static bnr_gramq gram_queues(const bnr_dev &d)
+{
+    bnr_gramq gq;
+    const int ntl = d.ntile * (d.ntile + 1) / 2;
+    gq.qoff[0] = 0;
+    for (int x = 0; x < 8; ++x) gq.qoff[x + 1] = gq.qoff[x] + ntl * ((d.ksplit - x + 7) / 8);
+    return gq;
+}
 static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
 {
     const bnr_dev &d = *x.shape;
@@ -534,7 +624,12 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
         hipEventRecord(e0, st);
     }
     const dim3 ggrid(round_up(ntl * d.ksplit, 8) * x.nb);
-    if (d.gram_kg == 4) {
+    if (x.gram_variant == 9 || (x.gram_variant == 0 && pipelined(x))) {
+        const unsigned *resv = pipelined(x) ? x.resv : nullptr;
+        const dim3 pgrid(3 * x.ncu);
+        if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_one>), pgrid, dim3(512), 0, st, bnr_one{d}, s, 1, gram_queues(d), resv, x.gctl);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_many>), pgrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb, gram_queues(d), resv, x.gctl);
+    } else if (d.gram_kg == 4) {
         if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), ggrid, dim3(1024), 0, st, bnr_one{d}, s, 1);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_many, 4>), ggrid, dim3(1024), 0, st, bnr_many{x.cds}, s, x.nb);
     } else {
@@ -553,12 +648,18 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
         }
     }
     if (timed) hipEventRecord(e1, st);
-    BNR_LAUNCH(k_gram_reduce, dim3(ntl, 8, x.nb), dim3(256), 0, st, x, s);
+    if (!left_looking(x)) BNR_LAUNCH(k_gram_reduce, dim3(ntl, 8, x.nb), dim3(256), 0, st, x, s);
 }
 static void launch_rhs(bnr_exec &x, int s) { BNR_LAUNCH(k_rhs, dim3(x.shape->n_pad / 64, 1, x.nb), dim3(256), 0, x.stream, x, s); }
-static void launch_chol(bnr_exec &x, int s, hipStream_t st)
+static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
 {
     const int nbk = x.shape->n_pad / BNR_NB;
+    if (left_looking(x)) {
+        const int nA = (nbk + 3) / 4, nB = nbk - 1;
+        for (int p = 0; p < nbk; ++p)
+            BNR_LAUNCH(k_chol_ll, dim3(x.nb, nA + (p + 1 < nbk ? nB : 0)), dim3(256), BNR_LL_LDS, st, x, p, s, nA, spin_us);
+        return;
+    }
     // update workgroups: one 32 x 32 block each while panels + updates of all members fit the chip in one round (two 256-thread
     // workgroups per CU); otherwise (large n, groups) 64 x 64 super blocks
     const int ncu = x.ncu;
@@ -615,19 +716,37 @@ static void launch_sweep(bnr_exec &x, int s, bool prev_tail)
     const bool timed = x.profiling != 0;
     const bool overlap = x.overlap != 0;
     hipStream_t sb = overlap ? x.stream2 : x.stream;
-    if (overlap) {
+    const bool pipe = pipelined(x);
+    hipEvent_t ej[3] = {nullptr, nullptr, nullptr};
+    if (pipe) {
+        // branch B: the Gram (persistent, off the reserved CUs); branch C: the factorization, gated on the Gram's progress; and in front
+        // of both a branch of one empty kernel: hipGraph runs the FIRST-captured forked branch to its end before it starts any other
+        // (profiles/round3_experiments_notes.txt A.3), so the first one must be nothing
+        hipEvent_t ef = next_event(x);
+        hipEventRecord(ef, x.stream);
+        hipStreamWaitEvent(x.stream4, ef, 0);
+        hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, x.stream4);
+        hipEventRecord(ej[0] = next_event(x), x.stream4);
+        hipStreamWaitEvent(x.stream2, ef, 0);
+        launch_gram(x, s, x.stream2, timed);
+        hipEventRecord(ej[1] = next_event(x), x.stream2);
+        hipStreamWaitEvent(x.stream3, ef, 0);
+        BNR_LAUNCH(k_gram_gate, dim3(x.nb), dim3(64), 72 * 1024, x.stream3, x, 0, x.gate_us);
+        launch_chol(x, s, x.stream3, x.gate_us);
+        hipEventRecord(ej[2] = next_event(x), x.stream3);
+    } else if (overlap) {
         hipEvent_t ef = next_event(x);
         hipEventRecord(ef, x.stream);
         hipStreamWaitEvent(x.stream2, ef, 0);
         launch_gram(x, s, sb, timed);
         launch_chol(x, s, sb);
-        hipEventRecord(next_event(x), x.stream2);
+        hipEventRecord(ej[0] = next_event(x), x.stream2);
     }
     if (prev_tail) launch_tail(x, s - 1, 1023, 0);
     launch_node(x, s, 3);
     launch_xpass(x, s, 3);
     launch_rhs(x, s);
-    if (overlap) hipStreamWaitEvent(x.stream, x.fj[x.fj_next - 1], 0);
+    if (overlap) { for (hipEvent_t e : ej) if (e) hipStreamWaitEvent(x.stream, e, 0); }
     else { launch_gram(x, s, sb, timed); launch_chol(x, s, sb); }
     launch_solve(x);
     launch_backproj(x, s, 7);
@@ -939,9 +1058,18 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
     if (!strcmp(name, "graph")) { x.use_graph = (int)value; return BNR_OK; }
     if (!strcmp(name, "overlap")) { x.overlap = (int)value; drop_graph(x); return BNR_OK; }
     if (!strcmp(name, "gram_variant")) {
-        if (value != 0 && value != 8 && value != 16) return fail(BNR_ERR_BAD_ARG, "gram_variant must be 0 (auto), 8 or 16");
+        if (value != 0 && value != 8 && value != 9 && value != 16) return fail(BNR_ERR_BAD_ARG, "gram_variant must be 0 (auto), 8, 9 (persistent) or 16");
         x.gram_variant = (int)value; drop_graph(x); return BNR_OK;
     }
+    if (!strcmp(name, "factor_variant")) {
+        if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "factor_variant must be -1 (auto), 0 (right-looking) or 1 (left-looking)");
+        x.factor_variant = (int)value; drop_graph(x); return BNR_OK;
+    }
+    if (!strcmp(name, "pipeline")) {
+        if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "pipeline must be -1 (auto), 0 or 1");
+        x.pipeline = (int)value; drop_graph(x); return BNR_OK;
+    }
+    if (!strcmp(name, "gate_us")) { if (value < 0 || value > 1000000) return fail(BNR_ERR_BAD_ARG, "gate_us out of range"); x.gate_us = (int)value; drop_graph(x); return BNR_OK; }
     if (!strcmp(name, "graph_k")) { if (value < 1 || value > 256) return fail(BNR_ERR_BAD_ARG, "graph_k out of range"); x.graph_k = (int)value; drop_graph(x); return BNR_OK; }
     if (!strcmp(name, "profiling")) { if (x.profiling != (int)value) drop_graph(x); x.profiling = (int)value; return BNR_OK; }
     return fail(BNR_ERR_BAD_ARG, std::string("unknown option ") + name);
@@ -1656,7 +1784,9 @@ static void launch_gram_only(bnr_chain *c)
 {
     const bnr_dev &d = c->d;
     const int ntl = d.ntile * (d.ntile + 1) / 2;
-    if (d.gram_kg == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), dim3(round_up(ntl * d.ksplit, 8)), dim3(1024), 0, c->x.stream, bnr_one{d}, 0, 1);
+    if (c->x.gram_variant == 9) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_one>), dim3(3 * c->x.ncu), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1, gram_queues(d), (const unsigned *)nullptr, c->x.gctl);
+    else if (c->x.gram_variant == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8<bnr_one>), dim3(round_up(ntl * d.ksplit, 8)), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1);
+    else if (d.gram_kg == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), dim3(round_up(ntl * d.ksplit, 8)), dim3(1024), 0, c->x.stream, bnr_one{d}, 0, 1);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 2>), dim3(round_up(ntl * d.ksplit, 8)), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1);
 }
 int bnr_chain_debug_time_gram(bnr_chain *c, int32_t reps, double *avg_us)
@@ -1673,6 +1803,7 @@ int bnr_chain_debug_time_gram(bnr_chain *c, int32_t reps, double *avg_us)
     hipEventRecord(e0, c->x.stream);
     for (int r = 0; r < reps; ++r) launch_gram_only(c);
     hipEventRecord(e1, c->x.stream);
+    HIPCHK(hipMemsetAsync(c->d.gprog, 0, sizeof(unsigned int) * (c->d.ntile + 1), c->x.stream));   // these launches were not consumed by a factorization
     HIPCHK(hipStreamSynchronize(c->x.stream));
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);

@@ -60,6 +60,9 @@ struct bnr_dev {
     long long *counters;         // [0] jitter, [1] nan_w, [2] sampler cap, [3] chol fail, [4..7] where, [8] branch-order violations
     unsigned long long *dbg;     // in-kernel s_memtime stamps (diagnostics only; never read by any kernel)
     unsigned int *stamp;         // one word per k_gram_reduce workgroup: iteration id of the Gram it finished (checked by k_chol_step)
+    unsigned int *gprog;         // Gram progress: [tc] = finished (tile, K slice) tasks of tile column tc of the running sweep (read by
+                                 // k_chol_ll, zeroed by its last launch); [ntile] = task queue head of k_gram8p; [ntile + 1] = sticky "a gate timed out"
+    const int *gmapc;            // k_gram8p: task list in tile-COLUMN order (tile | ks << 16): the factorization consumes G column by column
 };
 
 // How a sweep kernel finds its chain.  One chain: the struct travels by value in the kernel arguments (no dependent
@@ -81,7 +84,7 @@ __device__ __forceinline__ bnr_dev bnr_globalized(const bnr_dev *src)
     BNR_GLOBAL_PTR(pbase); BNR_GLOBAL_PTR(Wbuf); BNR_GLOBAL_PTR(sz); BNR_GLOBAL_PTR(PW); BNR_GLOBAL_PTR(PA); BNR_GLOBAL_PTR(PG);
     BNR_GLOBAL_PTR(Gpart); BNR_GLOBAL_PTR(E); BNR_GLOBAL_PTR(gmap); BNR_GLOBAL_PTR(a3); BNR_GLOBAL_PTR(xw); BNR_GLOBAL_PTR(a4);
     BNR_GLOBAL_PTR(res); BNR_GLOBAL_PTR(xg); BNR_GLOBAL_PTR(bw); BNR_GLOBAL_PTR(wv); BNR_GLOBAL_PTR(scal); BNR_GLOBAL_PTR(Minv);
-    BNR_GLOBAL_PTR(Psum); BNR_GLOBAL_PTR(counters); BNR_GLOBAL_PTR(dbg); BNR_GLOBAL_PTR(stamp);
+    BNR_GLOBAL_PTR(Psum); BNR_GLOBAL_PTR(counters); BNR_GLOBAL_PTR(dbg); BNR_GLOBAL_PTR(stamp); BNR_GLOBAL_PTR(gprog); BNR_GLOBAL_PTR(gmapc);
     return d;
 }
 struct bnr_one {
@@ -436,6 +439,12 @@ __global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int w
 // blockIdx.y = K slice across workgroups (split-K partials, summed by k_gram_reduce).
 typedef double bnr_d4 __attribute__((ext_vector_type(4)));
 typedef double bnr_d2 __attribute__((ext_vector_type(2)));
+// A Gram workgroup has stored its partial tile: count it for the tile's column (the factorization checks the count before its
+// first read of the column).  k_gram / k_gram8 are consumed after the kernel boundary: one relaxed atomic, no fence.
+__device__ __forceinline__ void bnr_gram_count(const bnr_dev &cd, int tj)
+{
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&cd.gprog[tj], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 #define BNR_GRAM_KB 16                // columns of X per staged batch (4 MFMA k-steps): one barrier per 16 MFMAs of a wave
 
 #ifndef BNR_GRAM_EXP
@@ -573,6 +582,7 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
         else out[idx] = sred[idx] + sred[BNR_GT * BNR_GT + idx];
     }
     BNR_GSTAMP(3);
+    bnr_gram_count(cd, tj);
 }
 
 // k_gram8: the same Gram, the same task map, the same summation order per element (bitwise the same partial tiles) -- for
@@ -582,22 +592,33 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
 // wave and 40 KiB of LDS per workgroup.  Hence batches of 8 columns (half the staging registers and half the LDS image of k_gram's
 // 16: 2 K-groups x 2 buffers x [I | J] x 8 x 64 doubles = 32 KiB; a barrier per 8 MFMAs of a wave) and a K-group reduction that needs
 // one tile of LDS instead of two (K-group 1 parks its tile, K-group 0 adds its registers and stores).
-template <class SRC>
-__global__ __launch_bounds__(512, 6) void k_gram8(const SRC chain_src, int s, int nchains)
+// a partial-tile element goes to memory either as a plain store (consumed after the kernel boundary) or written through to the
+// agent's coherence point (sc1), for a consumer that runs beside this kernel on another XCD
+template <bool WT>
+__device__ __forceinline__ void bnr_gstore(double *p, double v)
+{
+    if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+// what a Gram task needs besides the chain's S row and its partial-tile buffer: equal for all members of a lockstep group
+struct bnr_gram_geom { const double *X; int n_pad, q_pad, ksplit, q, ntile; };
+__device__ __forceinline__ bnr_gram_geom bnr_geom_of(const bnr_dev &cd) { return bnr_gram_geom{cd.X, cd.n_pad, cd.q_pad, cd.ksplit, cd.q, cd.ntile}; }
+// s_setprio takes an immediate: a wave-uniform level 0..2
+__device__ __forceinline__ void bnr_setprio3(int level)
+{
+    if (level == 0) __builtin_amdgcn_s_setprio(0);
+    else if (level == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(2);
+}
+// one (tile t = (ti, tj), K slice ks) task of the Gram with 8-column batches: 512 threads, sred = 32 KiB of LDS.
+// ROT >= 0 (persistent kernel): the workgroup's issue priority rotates through three levels every 8 batches, phase = ROT = its age
+// rank on the CU.  The arbiter serves equal priorities oldest-first, and a persistent workgroup never gets older relative to its
+// two neighbours: without the rotation the eldest runs a task in 61 us, the second in 100, the youngest in 175, and the launch
+// ends with the youngest ones' half-done tasks on an otherwise idle chip.
+template <bool WT>
+__device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const double *Sp, double *Gpart, int t, int ti, int tj, int ks, double *sred, int rot = -1)
 {
     constexpr int KG = 2, KB = 8;
-    const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
-    const int gchain = gr % nchains, gslot = (gr / nchains) * 8 + gx;
-    const bnr_dev &cd = chain_src.at(gchain);
-    __shared__ double sred[BNR_GT * BNR_GT];          // 32 KiB: staging buffers during the loop, then K-group 1's tile
-    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
-    const double *Sp = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
-    if (gslot >= cd.ksplit * (cd.ntile * (cd.ntile + 1) / 2)) return;
-    const int task = cd.gmap[gslot];
-    int t = task & 0xFFFF, ti = 0;
-    const int ks = task >> 16;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    int tj = t - ti * (ti + 1) / 2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kg = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
     const int kchunk = cd.q_pad / cd.ksplit;          // multiple of 8 KG (host guarantees)
@@ -652,12 +673,25 @@ __global__ __launch_bounds__(512, 6) void k_gram8(const SRC chain_src, int s, in
     BNR_G8_STORE(0);
     BNR_G8_LOAD(1);
     __syncthreads();
-    for (int b = 0; b < nbatch; ++b) {
-        BNR_G8_COMPUTE(b & 1, 0);
-        BNR_G8_STORE((b + 1) & 1);                 // batch b+1; its buffer was released by the last barrier
-        BNR_G8_LOAD(b + 2);
-        BNR_G8_COMPUTE(b & 1, 1);
-        __syncthreads();
+#define BNR_G8_BATCH(B)                                                                       \
+    do {                                                                                      \
+        BNR_G8_COMPUTE((B) & 1, 0);                                                           \
+        BNR_G8_STORE(((B) + 1) & 1);               /* batch b+1; its buffer was released by the last barrier */ \
+        BNR_G8_LOAD((B) + 2);                                                                 \
+        BNR_G8_COMPUTE((B) & 1, 1);                                                           \
+        __syncthreads();                                                                      \
+    } while (0)
+    if (rot < 0) {
+        for (int b = 0; b < nbatch; ++b) BNR_G8_BATCH(b);
+    } else {
+        // the same loop in chunks of 16 batches with the priority rotation between the chunks (kept out of the inner loop: a
+        // branch in there changes how the compiler interleaves the MFMAs with the LDS reads)
+        int b = 0;
+        for (int ch = 0; b < nbatch; ++ch) {
+            bnr_setprio3((rot + ch) % 3);
+            const int be = b + 16 < nbatch ? b + 16 : nbatch;
+            for (; b < be; ++b) BNR_G8_BATCH(b);
+        }
     }
     // tile element (i,j) lives at [j*64 + i]; this lane: j = wj*32 + jt*16 + (lane>>4) + 4 r, i = wi*32 + it*16 + (lane&15)
     const int jb = wj * 32 + (lane >> 4), ib = wi * 32 + (lane & 15);
@@ -672,14 +706,161 @@ __global__ __launch_bounds__(512, 6) void k_gram8(const SRC chain_src, int s, in
     }
     __syncthreads();
     if (kg == 0) {
-        double *out = cd.Gpart + ((size_t)ks * (cd.ntile * (cd.ntile + 1) / 2) + t) * (BNR_GT * BNR_GT);
+        double *out = Gpart + ((size_t)ks * (cd.ntile * (cd.ntile + 1) / 2) + t) * (BNR_GT * BNR_GT);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            out[(jb + 4 * r) * BNR_GT + ib] = c00[r] + sred[(jb + 4 * r) * BNR_GT + ib];
-            out[(jb + 4 * r) * BNR_GT + ib + 16] = c01[r] + sred[(jb + 4 * r) * BNR_GT + ib + 16];
-            out[(jb + 16 + 4 * r) * BNR_GT + ib] = c10[r] + sred[(jb + 16 + 4 * r) * BNR_GT + ib];
-            out[(jb + 16 + 4 * r) * BNR_GT + ib + 16] = c11[r] + sred[(jb + 16 + 4 * r) * BNR_GT + ib + 16];
+            bnr_gstore<WT>(out + (jb + 4 * r) * BNR_GT + ib, c00[r] + sred[(jb + 4 * r) * BNR_GT + ib]);
+            bnr_gstore<WT>(out + (jb + 4 * r) * BNR_GT + ib + 16, c01[r] + sred[(jb + 4 * r) * BNR_GT + ib + 16]);
+            bnr_gstore<WT>(out + (jb + 16 + 4 * r) * BNR_GT + ib, c10[r] + sred[(jb + 16 + 4 * r) * BNR_GT + ib]);
+            bnr_gstore<WT>(out + (jb + 16 + 4 * r) * BNR_GT + ib + 16, c11[r] + sred[(jb + 16 + 4 * r) * BNR_GT + ib + 16]);
         }
+    }
+}
+template <class SRC>
+__global__ __launch_bounds__(512, 6) void k_gram8(const SRC chain_src, int s, int nchains)
+{
+    const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
+    const int gchain = gr % nchains, gslot = (gr / nchains) * 8 + gx;
+    const bnr_dev &cd = chain_src.at(gchain);
+    __shared__ double sred[BNR_GT * BNR_GT];          // 32 KiB: staging buffers during the loop, then K-group 1's tile
+    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
+    const double *Sp = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
+    if (gslot >= cd.ksplit * (cd.ntile * (cd.ntile + 1) / 2)) return;
+    const int task = cd.gmap[gslot];
+    int t = task & 0xFFFF, ti = 0;
+    const int ks = task >> 16;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    int tj = t - ti * (ti + 1) / 2;
+    bnr_gram8_task<false>(bnr_geom_of(cd), Sp, cd.Gpart, t, ti, tj, ks, sred);
+    bnr_gram_count(cd, tj);
+}
+
+// k_gram8p: the same tasks, the same partial tiles bit for bit, as a PERSISTENT kernel that keeps off a set of reserved compute
+// units, so that the factorization (k_chol_ll on another stream) and the scalar branch of the sweep have CUs of their own while
+// the Gram saturates the matrix cores of the rest -- CU-masked streams do not survive graph capture, and a latency-bound wave that
+// shares a SIMD with MFMA-saturating waves is starved (profiles/round3_experiments_notes.txt A).
+//   grid = 3 x CUs workgroups (the kernel's residency): a workgroup that finds itself on a reserved CU (HW_REG_HW_ID /
+//   HW_REG_XCC_ID against the per-shader-engine masks `resv`, measured by k_cu_census at start-up) leaves at once; the others pull
+//   (tile, K slice, chain) tasks from eight queues, one per XCD: queue x lists the K slices ks = x mod 8 in tile-COLUMN order
+//   (the factorization consumes G column by column), chains innermost -- the workgroups of one XCD read the same slice of X
+//   through its L2; an XCD whose queue has run dry takes from the others.
+//   Results do not depend on who computes what: a task's arithmetic is fixed.  Progress: the last workgroup to leave (by ticket)
+//   finishes whatever is left in the queues, so the launch completes even if every other workgroup sat on a reserved CU.
+//   ctl (device words, zero between launches): [0..7] queue heads, [8] tickets.
+__device__ __forceinline__ unsigned bnr_hw_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v)); return v; }
+__device__ __forceinline__ unsigned bnr_xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 7u; }
+struct bnr_gramq { int qoff[9]; };                    // queue x = gmapc[qoff[x] .. qoff[x+1])
+// next task of a persistent Gram workgroup (ONE wavefront calls this): lanes 0..7 read the eight queue heads (plain loads: a dry
+// queue costs no atomic -- 768 workgroups that each probed every head at the end would queue up ~9 us per word), the first
+// queue with work at or after the own XCD is chosen and ONE atomic takes a ticket from it; -1 when every queue is dry.
+__device__ __forceinline__ void bnr_gram_fetch(unsigned *ctl, const int *s_qlen, unsigned xcc, int lane, int *s_task)
+{
+    int x = -1, id = 0;
+    for (;;) {
+        const unsigned head = lane < 8 ? __hip_atomic_load(&ctl[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const bool work = lane < 8 && (int)head < s_qlen[lane];
+        unsigned m = (unsigned)(__ballot(work) & 0xffull);
+        if (m == 0u) { x = -1; break; }
+        m = ((m >> xcc) | (m << (8u - xcc))) & 0xffu;                  // rotate: bit 0 = own XCD's queue
+        x = (int)((xcc + (unsigned)__builtin_ctz(m)) & 7u);
+        unsigned got = 0;
+        if (lane == 0) got = __hip_atomic_fetch_add(&ctl[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        id = __builtin_amdgcn_readfirstlane((int)got);
+        if (id < s_qlen[x]) break;                                     // else: the queue ran dry meanwhile, look again
+    }
+    if (lane == 0) { s_task[0] = x; s_task[1] = id; }
+}
+template <class SRC>
+__global__ __launch_bounds__(512, 6) void k_gram8p(const SRC chain_src, int s, int nchains, bnr_gramq gq, const unsigned *resv, unsigned *ctl)
+{
+    __shared__ double sred[BNR_GT * BNR_GT];
+    __shared__ int s_task[2], s_qlen[8], s_qoff[8], s_ticket;
+    // per member: the S row of this sweep, the partial-tile buffer, the progress words -- read once per workgroup, so that a task
+    // starts from two LDS reads instead of a chain of dependent global loads (descriptor -> plan entry -> row)
+    constexpr int TABMAX = 64;
+    __shared__ const double *s_Sp[TABMAX];
+    __shared__ double *s_Gp[TABMAX];
+    __shared__ unsigned int *s_prog[TABMAX];
+    const unsigned hw = bnr_hw_id(), xcc = bnr_xcc_id();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool reserved = resv && ((resv[xcc * 4 + ((hw >> 13) & 3u)] >> ((hw >> 8) & 15u)) & 1u);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) { s_qoff[x] = gq.qoff[x]; s_qlen[x] = (gq.qoff[x + 1] - gq.qoff[x]) * nchains; }
+        if (reserved) s_ticket = (int)__hip_atomic_fetch_add(&ctl[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const bool tabled = nchains <= TABMAX;
+    if (!reserved && tabled && (int)threadIdx.x < nchains) {
+        const bnr_dev &cm = chain_src.at(threadIdx.x);
+        const bnr_plan_entry Pm = cm.plan[cm.pbase[0] + s];
+        s_Sp[threadIdx.x] = cm.trace + (size_t)Pm.prev * cm.rowlen + cm.o_S;
+        s_Gp[threadIdx.x] = cm.Gpart;
+        s_prog[threadIdx.x] = cm.gprog;
+    }
+    const bnr_dev &c0 = chain_src.at(0);
+    const bnr_gram_geom geom = bnr_geom_of(c0);
+    const int *gmapc = c0.gmapc;
+    __syncthreads();
+    // a workgroup on a reserved CU leaves at once -- unless it is the last one out of the whole grid: then it finishes what is left
+    const bool sweeper = reserved && __builtin_amdgcn_readfirstlane(s_ticket) == (int)gridDim.x - 1;
+    if (reserved && !sweeper) return;
+    const int rank = (int)(blockIdx.x / (gridDim.x / 3u)) % 3;        // the dispatcher fills the CUs one workgroup per pass: age rank on the CU
+    if (wave == 4) bnr_gram_fetch(ctl, s_qlen, xcc, lane, s_task);
+    __syncthreads();
+    for (;;) {
+        const int x = __builtin_amdgcn_readfirstlane(s_task[0]), id = __builtin_amdgcn_readfirstlane(s_task[1]);
+        if (x < 0) break;
+        const int member = id % nchains;
+        const double *Sp;
+        double *Gp;
+        unsigned int *prog;
+        if (tabled && !sweeper) { Sp = s_Sp[member]; Gp = s_Gp[member]; prog = s_prog[member]; }
+        else {
+            const bnr_dev &cm = chain_src.at(member);
+            const bnr_plan_entry Pm = cm.plan[cm.pbase[0] + s];
+            Sp = cm.trace + (size_t)Pm.prev * cm.rowlen + cm.o_S; Gp = cm.Gpart; prog = cm.gprog;
+        }
+        // wave-uniform and known to be GLOBAL pointers (a pointer that went through LDS is generic: the compiler would emit flat loads,
+        // which count on lgkmcnt as well -- every wait for an LDS fragment would then wait for the S load's memory latency too)
+        {
+            const unsigned long long sp_ = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)Sp >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)Sp);
+            const unsigned long long gp_ = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)Gp >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)Gp);
+            Sp = (const double *)(__attribute__((address_space(1))) const void *)sp_;
+            Gp = (double *)(__attribute__((address_space(1))) void *)gp_;
+        }
+        const int task = __builtin_amdgcn_readfirstlane(gmapc[__builtin_amdgcn_readfirstlane(s_qoff[x]) + id / nchains]);   // wave-uniform: the loop's addressing stays on scalars
+        int t = task & 0xFFFF, ti = 0;
+        const int ks = task >> 16;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        const int tj = t - ti * (ti + 1) / 2;
+        __syncthreads();                              // everybody has read s_task
+        bnr_gram8_task<true>(geom, Sp, Gp, t, ti, tj, ks, sred, rank);
+        // K-group 1 is done once its tile is parked: its first wave fetches the next task while K-group 0 adds and stores
+        if (wave == 4) bnr_gram_fetch(ctl, s_qlen, xcc, lane, s_task);
+        // publish: every wave's write-through stores have landed (vmcnt), then ONE relaxed atomic on the column's counter
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&prog[tj], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (!sweeper) {
+        if (threadIdx.x == 0) s_ticket = (int)__hip_atomic_fetch_add(&ctl[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(s_ticket) != (int)gridDim.x - 1) return;
+    }
+    // last one out: everybody else has left its loop -- the queue heads and the ticket counter go back to zero for the next launch
+    if (threadIdx.x < 9) __hip_atomic_store(&ctl[threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// which compute units exist: every workgroup ORs its (XCD, shader engine) -> cu-id bit into out[xcc * 4 + se] and idles a little so
+// that the grid spreads over the whole chip
+__global__ void k_cu_census(unsigned *out, int spin)
+{
+    if (threadIdx.x == 0) {
+        const unsigned hw = bnr_hw_id(), xcc = bnr_xcc_id();
+        atomicOr(&out[xcc * 4 + ((hw >> 13) & 3u)], 1u << ((hw >> 8) & 15u));
+        atomicAdd(&out[32], 1u);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)spin) __builtin_amdgcn_s_sleep(4);
     }
 }
 
@@ -722,6 +903,7 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const SRC chain_src, int s)
         *(bnr_d2 *)(cd.E + (size_t)(np + r) + ld * c) = v;
     }
     if (threadIdx.x == 0) cd.stamp[blockIdx.x * 8 + blockIdx.y] = cd.plan[cd.pbase[0] + s].it;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x <= cd.ntile) cd.gprog[threadIdx.x] = 0u;   // all of G has been consumed
 }
 
 // ===================================================================================== blocked Cholesky + solve
@@ -1033,6 +1215,340 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
         }
     }
     BNR_STAMP(4);
+}
+
+// ----------------------------------------------------------------------------------------- left-looking factorization
+// k_chol_ll(p), p = 0..nbk-1: the same factorization of E = [G + I ; I] -> [L ; L^-T], the same arithmetic per element (every
+// element sees the panels' rank-32 updates in ascending panel order, eight MFMA k-steps each, then the same column sweep), but
+// block column j is touched for the FIRST time only at launch j-1 -- and there the K-split partials of the Gram are summed in
+// k_gram_reduce's order and the identity rows are generated on the fly: no reduction pass, no Y = I pass, and the factorization
+// of the leading columns can start while the Gram still computes the trailing ones (gate on cd.gprog, see bnr_gram_gate).
+//   role A (ceil(nbk/4) workgroups): FOUR sweeping wavefronts, one per SIMD, each owning one block row of panel p (matrix rows
+//       p+1.., identity rows 0..p): block (p,p) and the own block take panel p-1's update (MFMA, fragments from L2), then every
+//       wave sweeps [D ; own] -- lanes 0..31 redo the diagonal block, so nothing is handed over between waves or workgroups.
+//   role B (nbk-1 workgroups, one 32 x 32 block each, one 16 x 16 tile per wave): block column j = p+1 <- first touch - sum_{q<p} L[.,q] L[j,q]',
+//       i.e. everything except panel p's own update, which role A of launch p+1 applies.
+// Footprint per chain and launch: ceil(nbk/4) + nbk - 1 workgroups (19 at n = 500) against nbk + 1 + updates (17 + up to 120) before.
+#define BNR_L1W 48            // LDS column stride of the 32-row half-panels handed to the MFMA update (conflict-free fragments)
+#define BNR_LL_WAVE (BNR_NB * BNR_LP + 16 * BNR_L1W + 2 * BNR_NB)            // doubles per wave: sB | sL1 | sCol
+#define BNR_LL_LDS ((BNR_NB * BNR_LP + 16 * BNR_L1W + 4 * BNR_LL_WAVE) * sizeof(double))   // + shared sD | sL1D
+
+// First touch of G + I: the 32 x 32 block (rho, c), rho >= c, as MFMA accumulator fragments -- NT x NT tiles of 16 x 16 starting at
+// tile (at0, bt0) (columns at, rows bt; lane: row 16 bt + ln, columns 16 at + lq + 4 r) -- with the K-slice partials summed per
+// element in k_gram_reduce's order (ks ascending from 0.0, then + 1 on the diagonal).  The loop runs over the K slices with
+// all elements of a lane in flight per slice (the partial tiles come from HBM: one element at a time would cost ksplit x 16
+// dependent round trips).
+// fresh: the partial tiles were written while this kernel was already running (factorization beside the Gram), possibly through
+// another XCD's L2: read them past the own L2 (sc1 loads) -- an acquire fence instead would invalidate the whole L2 of this XCD,
+// once per wave, under everybody who works from it (measured: +30 us on every gated launch).
+__device__ __forceinline__ double bnr_ld_fresh(const double *p, bool fresh)
+{
+    return fresh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <int NT>
+__device__ __forceinline__ void bnr_gsum_frag(const bnr_dev &cd, int rho, int c, int at0, int bt0, int ln, int lq, bnr_d4 (&out)[NT][NT], bool fresh)
+{
+    const int ti = rho >> 1, tj = c >> 1, ntl = cd.ntile * (cd.ntile + 1) / 2;
+    const size_t tsz = BNR_GT * BNR_GT, plane = (size_t)ntl * tsz;
+    const double *src = cd.Gpart + (size_t)(ti * (ti + 1) / 2 + tj) * tsz + (size_t)((c & 1) * BNR_NB + 16 * at0 + lq) * BNR_GT + (rho & 1) * BNR_NB + 16 * bt0 + ln;
+#pragma unroll
+    for (int at = 0; at < NT; ++at)
+#pragma unroll
+        for (int bt = 0; bt < NT; ++bt) out[at][bt] = bnr_d4{0.0, 0.0, 0.0, 0.0};
+    // KU slices per round, all in flight; a slice past the last one is read again from the last plane and enters as + 0.0, which
+    // changes nothing (the running sum is never -0.0)
+    constexpr int KU = NT == 1 ? 8 : 4;
+    const int klast = cd.ksplit - 1;
+    for (int ks0 = 0; ks0 < cd.ksplit; ks0 += KU) {
+        bnr_d4 v[KU][NT][NT];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const size_t po = (size_t)(ks0 + u < klast ? ks0 + u : klast) * plane;
+#pragma unroll
+            for (int at = 0; at < NT; ++at)
+#pragma unroll
+                for (int bt = 0; bt < NT; ++bt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[u][at][bt][r] = bnr_ld_fresh(src + po + (size_t)(16 * at + 4 * r) * BNR_GT + 16 * bt, fresh);
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const double keep = (ks0 + u <= klast) ? 1.0 : 0.0;
+#pragma unroll
+            for (int at = 0; at < NT; ++at)
+#pragma unroll
+                for (int bt = 0; bt < NT; ++bt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) out[at][bt][r] += (ks0 + u <= klast) ? v[u][at][bt][r] : 0.0;
+            (void)keep;
+        }
+    }
+    if (rho == c) {
+#pragma unroll
+        for (int at = 0; at < NT; ++at)
+#pragma unroll
+            for (int bt = 0; bt < NT; ++bt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (16 * (bt0 + bt) + ln == 16 * (at0 + at) + lq + 4 * r) out[at][bt][r] += 1.0;
+    }
+}
+// Before the first read of tile column tc of Gpart: all its (tile, K slice) tasks of THIS sweep's Gram must have been published.
+// spin_us = 0: the Gram launch is complete (single-stream schedule, hooks) -- a shortfall is a stream-ordering violation.
+// spin_us > 0: the Gram may still be running beside this launch; lane 0 polls (relaxed, with s_sleep) for at most spin_us, then
+// gives up for good (sticky word, so that a schedule that was serialised after all costs ONE timeout, not one per gate).
+__device__ __forceinline__ void bnr_gram_gate(const bnr_dev &cd, int tc, int spin_us)
+{
+    if (threadIdx.x == 0) {
+        const unsigned need = (unsigned)((cd.ntile - tc) * cd.ksplit);
+        unsigned have = __hip_atomic_load(&cd.gprog[tc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (have < need && spin_us > 0 && __hip_atomic_load(&cd.gprog[cd.ntile + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_setprio(3);                 // a young wave among older MFMA-saturating ones is served last: one poll took 450 us
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), lim = 100ull * (unsigned long long)spin_us;
+            do {
+                __builtin_amdgcn_s_sleep(8);
+                have = __hip_atomic_load(&cd.gprog[tc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while (have < need && __builtin_amdgcn_s_memrealtime() - t0 < lim);
+            if (have < need) __hip_atomic_store(&cd.gprog[cd.ntile + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (have < need) atomicAdd((unsigned long long *)&cd.counters[8], 1ull);
+    }
+    __syncthreads();                                       // (the partial tiles are then read past the L2: bnr_ld_fresh)
+}
+
+// Pipelined schedule: the first node of the factorization branch.  If k_chol_ll(0) itself waited for the first tile column, its
+// workgroups would be dispatched all over the chip before the Gram's are (both branches start together) and sit there spinning: a
+// Gram CU that hosts one of them has room for ONE Gram workgroup instead of three (measured: Gram 335 instead of 210 us, and the
+// column it waits for arrives after 220 us instead of 60).  One small wavefront per chain waits instead; 72 KiB of dynamic LDS
+// keep it off the Gram's CUs (a young wave on a SIMD that older MFMA-saturating waves keep busy is starved).
+template <class SRC>
+__global__ __launch_bounds__(64) void k_gram_gate(const SRC chain_src, int tc, int spin_us)
+{
+    const bnr_dev &cd = chain_src.get_x();               // grid = chains
+    bnr_gram_gate(cd, tc, spin_us);
+}
+template <class SRC>
+__global__ __launch_bounds__(256, 1) void k_chol_ll(const SRC chain_src, int p, int s, int nA, int spin_us)
+{
+    const bnr_dev &cd = chain_src.get_x();               // grid = (chains, workgroups)
+    extern __shared__ double shll[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nbk = cd.n_pad / BNR_NB;
+    const size_t ld = bnr_ldE(cd.n_pad);
+    const int pc = p * BNR_NB, kc = pc - BNR_NB;
+    const int ln = lane & 15, lq = lane >> 4;
+    double *E = cd.E;
+    (void)s;
+    if ((int)blockIdx.y >= nA) {
+        // ------------------------------------------------ role B: block column j = p + 1, everything but panel p's update
+        const int j = p + 1;
+        if (j >= nbk) return;
+        if (((j & 1) == 0 || p == 0)) bnr_gram_gate(cd, j >> 1, spin_us);      // first touch of tile column j/2 (odd j > 1: gated one launch ago)
+        const int a = (int)blockIdx.y - nA;                                    // matrix rows j..nbk-1, then identity rows 0..p-1
+        const bool ident = a >= nbk - j;
+        const int r_id = a - (nbk - j);
+        const int R = ident ? nbk + r_id : j + a, q0 = ident ? r_id : 0;
+        const int at = wave >> 1, bt = wave & 1;                               // this wave's 16 x 16 tile: columns at, rows bt
+        double *cp = E + (size_t)(R * BNR_NB + 16 * bt + ln) + ld * (size_t)(j * BNR_NB + 16 * at + lq);
+        bnr_d4 c = {0.0, 0.0, 0.0, 0.0};
+        const double *colrows = E + (size_t)(j * BNR_NB + 16 * at + ln) + ld * (size_t)lq, *rowrows = E + (size_t)(R * BNR_NB + 16 * bt + ln) + ld * (size_t)lq;
+        // The panels q = q0..p-1 are applied in order (one dependent MFMA chain); what bounds this loop is the L2 latency of the
+        // fragment loads, so the fragments of the next three panels are kept in flight (a ring of four register sets), and the
+        // steady state has no branches (a branch makes the compiler drain the loads in flight).  Loads past the last panel are
+        // clamped to it and never used.
+        double fa[4][8], fb[4][8];
+#define BNR_LLB_LOAD(SET, Q)                                                                              \
+        do {                                                                                              \
+            const size_t o_ = ld * (size_t)((Q) * BNR_NB);                                                \
+            _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) { fa[SET][ks] = colrows[o_ + ld * (size_t)(4 * ks)]; fb[SET][ks] = rowrows[o_ + ld * (size_t)(4 * ks)]; } \
+        } while (0)
+#define BNR_LLB_MFMA(SET)                                                                                 \
+        do {                                                                                              \
+            _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-fa[SET][ks], fb[SET][ks], c, 0, 0, 0); \
+        } while (0)
+        const int last = p - 1;
+        int q = q0;
+        if (p > 0) {
+            BNR_LLB_LOAD(0, q < last ? q : last);
+            BNR_LLB_LOAD(1, q + 1 < last ? q + 1 : last);
+            BNR_LLB_LOAD(2, q + 2 < last ? q + 2 : last);
+        }
+        if (!ident) {
+            bnr_d4 t1[1][1];
+            bnr_gsum_frag<1>(cd, R, j, at, bt, ln, lq, t1, spin_us > 0);                    // first touch: the K-slice partials of G (+ I)
+            c = t1[0][0];
+        }
+        if (p > 0) {
+            for (; q + 4 <= p; q += 4) {
+                BNR_LLB_LOAD(3, q + 3);
+                BNR_LLB_MFMA(0);
+                BNR_LLB_LOAD(0, q + 4 < last ? q + 4 : last);
+                BNR_LLB_MFMA(1);
+                BNR_LLB_LOAD(1, q + 5 < last ? q + 5 : last);
+                BNR_LLB_MFMA(2);
+                BNR_LLB_LOAD(2, q + 6 < last ? q + 6 : last);
+                BNR_LLB_MFMA(3);
+            }
+            if (q < p) BNR_LLB_MFMA(0);
+            if (q + 1 < p) BNR_LLB_MFMA(1);
+            if (q + 2 < p) BNR_LLB_MFMA(2);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cp[ld * (size_t)(4 * r)] = c[r];
+        return;
+    }
+    // ---------------------------------------------------- role A: four sweeping wavefronts
+    double *sD = shll, *sL1D = shll + BNR_NB * BNR_LP;
+    double *mine = shll + BNR_NB * BNR_LP + 16 * BNR_L1W + wave * BNR_LL_WAVE;
+    double *sB = mine, *sL1 = mine + BNR_NB * BNR_LP;
+    double (*sCol)[BNR_NB] = (double (*)[BNR_NB])(mine + BNR_NB * BNR_LP + 16 * BNR_L1W);
+#ifdef BNR_STAMPS
+#define BNR_LSTAMP(slot) do { if (blockIdx.y == 0 && tid == 0) cd.dbg[p * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BNR_LSTAMP(slot) do { } while (0)
+#endif
+    BNR_LSTAMP(0);
+    if (p == 0) bnr_gram_gate(cd, 0, spin_us);
+    const int a = 4 * (int)blockIdx.y + wave;                                  // matrix rows p+1..nbk-1, then identity rows 0..p
+    const bool active = a < nbk;                                               // a spare wave runs along on block row p (valid memory) and stores nothing
+    const bool ident = active && a >= nbk - 1 - p;
+    const int r_id = a - (nbk - 1 - p);
+    const int R = !active ? p : (ident ? nbk + r_id : p + 1 + a);
+    {
+        // Block (p,p): one 16 x 16 tile per wave (columns mt, rows nt); own block: 2 x 2 tiles -- both as MFMA accumulator
+        // fragments.  Identity rows: row p is the identity block itself and takes no update, row p-1 starts from zero, both
+        // without reading E (nobody initialises Y); rows < p-1 were prepared by role B of the previous launch.
+        const int mt = wave >> 1, nt = wave & 1;
+        bnr_d4 cD, c[2][2];
+        if (p == 0) {
+            bnr_d4 t1[1][1];
+            bnr_gsum_frag<1>(cd, 0, 0, mt, nt, ln, lq, t1, spin_us > 0);
+            cD = t1[0][0];
+            if (!ident) bnr_gsum_frag<2>(cd, active ? R : 0, 0, 0, 0, ln, lq, c, spin_us > 0);
+        } else {
+            // every global load of the launch is issued here, back to back, before the first wait: one L2 round trip
+            const bool fresh = ident && r_id >= p - 1, skip = ident && r_id == p;
+            const double *dp = E + (size_t)(pc + nt * 16 + ln) + ld * (size_t)(pc + mt * 16 + lq);
+            const double *bp = E + (size_t)((fresh ? p : R) * BNR_NB + ln) + ld * (size_t)(pc + lq);
+            const double *colrows = E + (size_t)(pc + ln) + ld * (size_t)(kc + lq), *rowrows = E + (size_t)((skip ? p : R) * BNR_NB + ln) + ld * (size_t)(kc + lq);
+            double av[2][8], bv[2][8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const size_t o = ld * (size_t)(4 * ks);
+                av[0][ks] = colrows[o]; av[1][ks] = colrows[o + 16]; bv[0][ks] = rowrows[o]; bv[1][ks] = rowrows[o + 16];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cD[r] = dp[ld * (size_t)(4 * r)];
+#pragma unroll
+            for (int at = 0; at < 2; ++at)
+#pragma unroll
+                for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c[at][bt][r] = bp[(size_t)(16 * bt) + ld * (size_t)(16 * at + 4 * r)];
+            // the diagonal block's fragments are rows of L[p, p-1] as well: column side = av[mt], row side = av[nt]
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) cD = __builtin_amdgcn_mfma_f64_16x16x4f64(-(mt ? av[1][ks] : av[0][ks]), nt ? av[1][ks] : av[0][ks], cD, 0, 0, 0);
+            if (fresh) {
+#pragma unroll
+                for (int at = 0; at < 2; ++at)
+#pragma unroll
+                    for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) c[at][bt][r] = (skip && 16 * bt + ln == 16 * at + lq + 4 * r) ? 1.0 : 0.0;
+            }
+            if (!skip) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                    for (int at = 0; at < 2; ++at)
+#pragma unroll
+                        for (int bt = 0; bt < 2; ++bt) c[at][bt] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[at][ks], bv[bt][ks], c[at][bt], 0, 0, 0);
+            }
+        }
+        if (p == 0 && ident) {                                                 // p = 0: the only identity row is row 0 = the identity block
+#pragma unroll
+            for (int at = 0; at < 2; ++at)
+#pragma unroll
+                for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c[at][bt][r] = (16 * bt + ln == 16 * at + lq + 4 * r) ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sD[(nt * 16 + ln) + BNR_LP * (mt * 16 + lq + 4 * r)] = cD[r];
+#pragma unroll
+        for (int at = 0; at < 2; ++at)
+#pragma unroll
+            for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sB[(16 * bt + ln) + BNR_LP * (16 * at + lq + 4 * r)] = c[at][bt][r];
+    }
+    BNR_LSTAMP(1);
+    __syncthreads();
+    BNR_LSTAMP(2);
+    const int rr = lane & 31;
+    const double *src = (lane < 32) ? sD : sB;
+    double a1[16], a2[16];
+    int bad = 0;
+    {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a1[c] = src[rr + BNR_LP * c];
+        bad = bnr_sweep16<0>(a1, lane, sCol);
+        // first half of the panel for the MFMA update of the second: diagonal rows once per workgroup, own rows per wave
+        if (lane >= 32) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sL1[c * BNR_L1W + rr] = a1[c];
+        } else if (wave == 0) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sL1D[c * BNR_L1W + rr] = a1[c];
+        }
+    }
+    BNR_LSTAMP(3);
+    __syncthreads();
+    {
+        //   A[:, 16:32] -= L[:, 0:16] L[16:32, 0:16]'   -- diagonal rows: waves 0 and 1 (16 rows each), own rows: 2 tiles per wave
+        double avk[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) avk[ks] = sL1D[(4 * ks + lq) * BNR_L1W + 16 + ln];      // column side: rows 16..31 of the diagonal block
+        if (wave < 2) {
+            const int rowb = wave * 16;
+            bnr_d4 c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] = sD[(rowb + ln) + BNR_LP * (16 + lq + 4 * r)];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-avk[ks], sL1D[(4 * ks + lq) * BNR_L1W + rowb + ln], c, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sD[(rowb + ln) + BNR_LP * (16 + lq + 4 * r)] = c[r];
+        }
+        {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bnr_d4 c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c[r] = sB[(t * 16 + ln) + BNR_LP * (16 + lq + 4 * r)];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-avk[ks], sL1[(4 * ks + lq) * BNR_L1W + t * 16 + ln], c, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sB[(t * 16 + ln) + BNR_LP * (16 + lq + 4 * r)] = c[r];
+            }
+        }
+    }
+    __syncthreads();
+    BNR_LSTAMP(4);
+    {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a2[c] = src[rr + BNR_LP * (16 + c)];
+        bad |= bnr_sweep16<16>(a2, lane, sCol);
+        BNR_LSTAMP(5);
+        // the swept own block B L_D^-T straight from the registers (lane = row); the factored diagonal block is needed by nobody
+        if (active && lane >= 32) {
+            double *op = E + (size_t)(R * BNR_NB + rr) + ld * (size_t)pc;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { op[ld * (size_t)c] = a1[c]; op[ld * (size_t)(16 + c)] = a2[c]; }
+        }
+    }
+    BNR_LSTAMP(6);
+    if (bad && tid == 0 && blockIdx.y == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[7], 1ull); }
+    // the last launch has seen every gate pass: zero the progress words for the next sweep's Gram
+    if (p == nbk - 1 && blockIdx.y == 0 && tid <= cd.ntile) cd.gprog[tid] = 0u;
 }
 
 // Right-hand side: finishes the GEMVs of k_xpass and forms b = a1 - a3 (gibbs.jl:432-434):
@@ -1546,6 +2062,7 @@ __global__ __launch_bounds__(1024) void k_tail(const SRC chain_src, int s, int m
 
 // advances the plan base after a batch of sweeps (last node of the captured graph)
 __global__ void k_advance(const bnr_dev *cds, int by) { if (threadIdx.x == 0) ((int *)cds[blockIdx.x].pbase)[0] += by; }   // grid = chains
+__global__ void k_nop() { }
 __global__ void k_stamp(unsigned long long *dbg, int slot) { if (threadIdx.x == 0) dbg[slot] = __builtin_amdgcn_s_memrealtime(); }
 // the event counters of all members of a launch into one block (one device -> host copy per run call); grid = chains, 16 threads
 __global__ void k_gather_counters(const bnr_dev *cds, long long *out) { out[blockIdx.x * 16 + threadIdx.x] = cds[blockIdx.x].counters[threadIdx.x]; }

@@ -955,6 +955,41 @@ def test_gram_kernels_write_the_same_tiles(gpu):
             assert np.array_equal(tabs[16][0][k], tabs[16][1][k]), ("group vs alone", n, V, R, k)
 
 
+def test_factorization_and_schedule_variants_are_bitwise_equal(gpu):
+    """The opt-in variants of round 3 -- the left-looking factorization k_chol_ll (K-split partials summed on the first touch, no
+    k_gram_reduce), the persistent Gram k_gram8p (tasks from per-XCD queues, keeps off the reserved compute units) and the
+    pipelined schedule (factorization BESIDE the Gram, gated on its progress per tile column, three graph branches) -- give bitwise
+    the tables of the default right-looking path (gibbs.jl:434), alone and as members of a lockstep group, eagerly and from graphs."""
+    for (n, V, R) in [(70, 19, 5), (193, 30, 5), (64, 9, 2), (500, 40, 4)]:
+        X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=7)
+        tabs = {}
+        for name, opts in (("right", {"factor_variant": 0}), ("left", {"factor_variant": 1, "pipeline": 0}),
+                           ("left, persistent Gram", {"factor_variant": 1, "pipeline": 0, "gram_variant": 9}),
+                           ("pipelined", {"factor_variant": 1, "pipeline": 1}), ("pipelined, eager", {"factor_variant": 1, "pipeline": 1, "graph": 0})):
+            ch = bnr_amd.Chain(X, y, R, 6, 3, 1)
+            mates = [bnr_amd.Chain.like(ch, 3, c, 6) for c in (2, 3)]
+            for c in [ch] + mates:
+                c.init_prior()
+            g = bnr_amd.Group([mates[0], ch, mates[1]])
+            solo = bnr_amd.Chain.like(ch, 3, 1, 6)
+            solo.init_prior()
+            for k, v in opts.items():
+                g.set_option(k, v)
+                solo.set_option(k, v)
+            g.run(2, 6, 6)
+            solo.run(2, 6, 6)
+            tabs[name] = (ch.fetch(), solo.fetch())
+            assert ch.counters()["chol_fail"] == 0 and solo.counters()["chol_fail"] == 0
+            g.close()
+            for c in [ch, solo] + mates:
+                c.close()
+        for name, (grp, alone) in tabs.items():
+            for k in bo.COLUMNS:
+                assert np.array_equal(grp[k], tabs["right"][0][k]), (name, "group", n, V, R, k)
+                assert np.array_equal(alone[k], tabs["right"][1][k]), (name, "alone", n, V, R, k)
+                assert np.array_equal(grp[k], alone[k]), (name, "group vs alone", n, V, R, k)
+
+
 def test_prepare_never_changes_results(gpu, test1):
     """bnr_chain_prepare / bnr_group_prepare capture the graphs and replay them once on scratch rows: tables, iteration
     counters and event counters of a chain alone and of a lockstep group are bitwise what they are without it -- called
