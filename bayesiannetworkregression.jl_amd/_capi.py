@@ -9,7 +9,7 @@ import numpy as np
 
 from ._build import LIB
 
-BNR_OK = 0
+BNR_OK, BNR_ERR_BAD_ARG, BNR_ERR_HIP, BNR_ERR_CHOLESKY, BNR_ERR_SAMPLER = 0, 1, 2, 3, 4
 ERRORS = {1: "bad argument", 2: "HIP error", 3: "Cholesky failed after jitter", 4: "sampler attempt cap"}
 
 
@@ -97,6 +97,23 @@ for _u in ("tau2", "u_xi", "gamma", "D", "theta", "Delta", "M", "mu", "Lambda", 
 EXPORTS = sorted(_SIGS)
 
 
+_foreign_hip = None      # set by lib(): why chains must not be created in this process (GPU-free entry points stay usable)
+
+
+def _mapped(needle):
+    """paths of the shared objects in this process whose name contains `needle` (from /proc/self/maps)"""
+    out = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                parts = line.split()
+                if len(parts) >= 6 and needle in os.path.basename(parts[5]) and parts[5] not in out:
+                    out.append(parts[5])
+    except OSError:
+        pass
+    return out
+
+
 def lib():
     """Load libbnr_hip.so; raises if it has not been built (run __graft_entry__.build())."""
     global _lib
@@ -104,7 +121,19 @@ def lib():
         if not os.path.exists(LIB):
             raise ImportError("libbnr_hip.so is missing at %s -- build it with `python -c 'import __graft_entry__ as g; "
                               "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB)
+        # Load order: the process serves every libamdhip64 user from the FIRST copy that was mapped.  A torch wheel carries its own
+        # ROCm runtime; if it is already in the process, libbnr_hip.so would silently run on that one (its graph capture of the
+        # two-branch sweep has only ever been validated on the runtime the library was built against, and round 2 saw captures
+        # crash under the wheel's 7.0 runtime).  Refuse with a clear message instead (BNR_ALLOW_FOREIGN_HIP=1 overrides).
+        before = _mapped("libamdhip64")
         L = C.CDLL(LIB)
+        after = _mapped("libamdhip64")
+        foreign = [p_ for p_ in before if not os.path.realpath(p_).startswith(os.path.realpath(os.environ.get("ROCM_PATH", "/opt/rocm")))]
+        global _foreign_hip
+        if foreign and after == before and not os.environ.get("BNR_ALLOW_FOREIGN_HIP"):
+            _foreign_hip = ("libbnr_hip.so was loaded after another HIP runtime (%s) and is bound to it instead of %s/lib: load the library "
+                            "(bnr_amd._capi.lib(), or create the chains) BEFORE importing torch, or set BNR_ALLOW_FOREIGN_HIP=1 to run on the "
+                            "foreign runtime" % (", ".join(foreign), os.environ.get("ROCM_PATH", "/opt/rocm")))
         for name, (res, args) in _SIGS.items():
             f = getattr(L, name)
             f.restype = res
@@ -204,6 +233,8 @@ class Chain:
         self.h = C.c_void_p()
         hy = Hyper(eta, zeta, iota, aDelta, bDelta, float(nu))
         self.L = lib()
+        if _foreign_hip:
+            raise BnrError(BNR_ERR_HIP, _foreign_hip)
         common = (_ptr(yf), C.byref(hy), C.c_uint64(int(seed) & (2**64 - 1)), int(chain_id), int(device), int(tot_save), C.byref(self.h))
         if xi.from_matrices:
             ptrs = (C.c_void_p * n)(*[m.ctypes.data for m in xi.data])

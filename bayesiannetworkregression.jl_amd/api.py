@@ -1,5 +1,9 @@
 """Host-side mirror of the reference's public and chain-driver API for the Gibbs hot path, over the C ABI.
 
+SPDX-License-Identifier: GPL-2.0-or-later.  Provenance: `generate_samples` / `generate_samples_dbl` restate the schedule arithmetic of
+BayesianNetworkRegression.jl (GPL-2.0; S. Ozminkowski, C. Solis-Lemus), src/gibbs.jl:955-1013 and 1119-1190 -- the `num2move` rules,
+`tot_sze`, `first_index` and the messages -- because a drop-in for that API must walk the same rows; the rest is written for this repository.
+
 Julia is not available in this image, so the thin host layer a Julia user would get from julia/BNRHip.jl
 (ccall) is mirrored here in Python (ctypes) with the reference's names, argument meaning and defaults:
 

@@ -18,6 +18,15 @@
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+// HIP calls inside the launch helpers (event records, stream waits): their first failure is kept and reported by the next
+// check_launch(), like a failed kernel launch
+static thread_local hipError_t g_noted = hipSuccess;
+static thread_local const char *g_noted_what = nullptr;
+#define HIPNOTE(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess && g_noted == hipSuccess) { g_noted = _e; g_noted_what = #expr; }         \
+    } while (0)
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \
@@ -220,7 +229,7 @@ static int upload_x(bnr_chain *c, const x_source &src, double *Xd)
         }
         e = hipStreamSynchronize(c->x.stream);
     }
-    hipFree(raw);
+    (void)hipFree(raw);
     if (e != hipSuccess) return fail(BNR_ERR_HIP, std::string("upload of X: ") + hipGetErrorString(e));
     return check_launch("k_x_convert");
 }
@@ -331,8 +340,8 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
             std::vector<int> hk(d.q), hl(d.q);
             int e = 0;
             for (int k = 0; k < V; ++k) for (int l = k; l < V; ++l, ++e) { hk[e] = k; hl[e] = l; }
-            hipMemcpy(ek, hk.data(), d.q * sizeof(int), hipMemcpyHostToDevice);
-            hipMemcpy(el, hl.data(), d.q * sizeof(int), hipMemcpyHostToDevice);
+            HIPNOTE(hipMemcpy(ek, hk.data(), d.q * sizeof(int), hipMemcpyHostToDevice));
+            HIPNOTE(hipMemcpy(el, hl.data(), d.q * sizeof(int), hipMemcpyHostToDevice));
         }
         d.ek = ek; d.el = el;
         TRY(upload_x(c, xs, Xd));
@@ -357,7 +366,7 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
                 map[i] = queue[xq][head[xq]++];
             }
             TRY(in_alloc((void **)&gm, sizeof(int) * ntask));
-            hipMemcpy(gm, map.data(), ntask * sizeof(int), hipMemcpyHostToDevice);
+            HIPNOTE(hipMemcpy(gm, map.data(), ntask * sizeof(int), hipMemcpyHostToDevice));
             // k_gram8p: eight queues (K slices ks = x mod 8 on XCD x), each in tile-COLUMN order; offsets: gram_queues()
             std::vector<int> mapc;
             for (int x = 0; x < 8; ++x)
@@ -365,7 +374,7 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
                     for (int ti = tc; ti < d.ntile; ++ti)
                         for (int ks = x; ks < d.ksplit; ks += 8) mapc.push_back((ti * (ti + 1) / 2 + tc) | (ks << 16));
             TRY(in_alloc((void **)&gmc, sizeof(int) * ntask));
-            hipMemcpy(gmc, mapc.data(), ntask * sizeof(int), hipMemcpyHostToDevice);
+            HIPNOTE(hipMemcpy(gmc, mapc.data(), ntask * sizeof(int), hipMemcpyHostToDevice));
         }
         d.X = Xd; d.y = yd; d.ek = ek; d.el = el; d.gmap = gm; d.gmapc = gmc;
     }
@@ -469,7 +478,7 @@ static const unsigned *reserved_cus(int device, int per_se)
 
 static void drop_graph(bnr_exec &x)
 {
-    for (auto &r : x.ladder) { if (r.gexec) hipGraphExecDestroy(r.gexec); if (r.graph) hipGraphDestroy(r.graph); }
+    for (auto &r : x.ladder) { if (r.gexec) (void)hipGraphExecDestroy(r.gexec); if (r.graph) (void)hipGraphDestroy(r.graph); }
     x.ladder.clear();
 }
 static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape)
@@ -494,14 +503,14 @@ static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape)
 }
 static void exec_free(bnr_exec &x)
 {
-    if (x.stream) { hipStreamSynchronize(x.stream); }
-    if (x.stream2) { hipStreamSynchronize(x.stream2); }
-    if (x.stream3) { hipStreamSynchronize(x.stream3); hipStreamDestroy(x.stream3); }
-    if (x.stream4) { hipStreamSynchronize(x.stream4); hipStreamDestroy(x.stream4); }
+    if (x.stream) { (void)hipStreamSynchronize(x.stream); }
+    if (x.stream2) { (void)hipStreamSynchronize(x.stream2); }
+    if (x.stream3) { (void)hipStreamSynchronize(x.stream3); (void)hipStreamDestroy(x.stream3); }
+    if (x.stream4) { (void)hipStreamSynchronize(x.stream4); (void)hipStreamDestroy(x.stream4); }
     if (x.gctl) hipFree(x.gctl);
     drop_graph(x);
-    if (x.stream) hipStreamDestroy(x.stream);
-    if (x.stream2) hipStreamDestroy(x.stream2);
+    if (x.stream) (void)hipStreamDestroy(x.stream);
+    if (x.stream2) (void)hipStreamDestroy(x.stream2);
     for (hipEvent_t e : x.fj) hipEventDestroy(e);
     for (hipEvent_t e : x.ev) hipEventDestroy(e);
     if (x.cds) hipFree(x.cds);
@@ -525,10 +534,10 @@ int bnr_group_destroy(bnr_group *g);
 int bnr_chain_destroy(bnr_chain *c)
 {
     if (!c) return BNR_OK;
-    hipSetDevice(c->device);
+    HIPNOTE(hipSetDevice(c->device));
     if (c->group) {                                      // a group cannot run without a member: dissolve it (the handle stays valid)
         bnr_group *g = c->group;
-        hipStreamSynchronize(g->x.stream);
+        HIPNOTE(hipStreamSynchronize(g->x.stream));
         for (bnr_chain *m : g->m) m->group = nullptr;
         g->m.clear();
     }
@@ -551,12 +560,13 @@ static int ensure_plan(bnr_chain *c, int count)
     HIPCHK(hipMalloc((void **)&nd, sizeof(bnr_plan_entry) * cap));
     HIPCHK(hipHostMalloc((void **)&np, sizeof(bnr_plan_entry) * cap));
     forget_alloc(c, c->plan_dev);
-    hipFree(c->plan_dev);
-    hipHostFree(c->plan_pin);
+    (void)hipFree(c->plan_dev);
+    (void)hipHostFree(c->plan_pin);
     c->allocs.push_back(nd);
     c->plan_dev = nd; c->plan_pin = np; c->plan_cap = cap;
     c->d.plan = nd;
     drop_graph(c->x);                       // one chain: the struct is a by-value kernel argument baked into the captured graph
+    if (c->group) drop_graph(c->group->x);  // ... also into the graphs of a ONE-member group (bnr_one there too)
     return sync_dev(c);
 }
 // st: the stream the sweeps that read this plan are issued on (the chain's own, or its group's: no cross-stream hand-over)
@@ -570,6 +580,11 @@ static int upload_plan(bnr_chain *c, int count, hipStream_t st = nullptr)
 static int check_launch(const char *what)
 {
     hipError_t e = hipGetLastError();
+    if (g_noted != hipSuccess) {
+        const hipError_t ne = g_noted;
+        g_noted = hipSuccess;
+        return fail(BNR_ERR_HIP, std::string(what) + ": " + (g_noted_what ? g_noted_what : "HIP call") + ": " + hipGetErrorString(ne));
+    }
     if (e != hipSuccess) return fail(BNR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
     return BNR_OK;
 }
@@ -621,7 +636,7 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
     }
     if (timed) {
         e0 = x.ev[2 * s]; e1 = x.ev[2 * s + 1];
-        hipEventRecord(e0, st);
+        HIPNOTE(hipEventRecord(e0, st));
     }
     const dim3 ggrid(round_up(ntl * d.ksplit, 8) * x.nb);
     if (x.gram_variant == 9 || (x.gram_variant == 0 && pipelined(x))) {
@@ -647,7 +662,7 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_many, 2>), ggrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb);
         }
     }
-    if (timed) hipEventRecord(e1, st);
+    if (timed) HIPNOTE(hipEventRecord(e1, st));
     if (!left_looking(x)) BNR_LAUNCH(k_gram_reduce, dim3(ntl, 8, x.nb), dim3(256), 0, st, x, s);
 }
 static void launch_rhs(bnr_exec &x, int s) { BNR_LAUNCH(k_rhs, dim3(x.shape->n_pad / 64, 1, x.nb), dim3(256), 0, x.stream, x, s); }
@@ -696,7 +711,7 @@ static hipEvent_t next_event(bnr_exec &x)
 {
     if (x.fj_next >= x.fj.size()) {
         hipEvent_t e = nullptr;
-        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);       // a failure surfaces as the launch error of the record/wait below
+        HIPNOTE(hipEventCreateWithFlags(&e, hipEventDisableTiming));    // a failure is reported by the next check_launch()
         x.fj.push_back(e);
     }
     return x.fj[x.fj_next++];
@@ -723,30 +738,30 @@ static void launch_sweep(bnr_exec &x, int s, bool prev_tail)
         // of both a branch of one empty kernel: hipGraph runs the FIRST-captured forked branch to its end before it starts any other
         // (profiles/round3_experiments_notes.txt A.3), so the first one must be nothing
         hipEvent_t ef = next_event(x);
-        hipEventRecord(ef, x.stream);
-        hipStreamWaitEvent(x.stream4, ef, 0);
+        HIPNOTE(hipEventRecord(ef, x.stream));
+        HIPNOTE(hipStreamWaitEvent(x.stream4, ef, 0));
         hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, x.stream4);
-        hipEventRecord(ej[0] = next_event(x), x.stream4);
-        hipStreamWaitEvent(x.stream2, ef, 0);
+        HIPNOTE(hipEventRecord(ej[0] = next_event(x), x.stream4));
+        HIPNOTE(hipStreamWaitEvent(x.stream2, ef, 0));
         launch_gram(x, s, x.stream2, timed);
-        hipEventRecord(ej[1] = next_event(x), x.stream2);
-        hipStreamWaitEvent(x.stream3, ef, 0);
+        HIPNOTE(hipEventRecord(ej[1] = next_event(x), x.stream2));
+        HIPNOTE(hipStreamWaitEvent(x.stream3, ef, 0));
         BNR_LAUNCH(k_gram_gate, dim3(x.nb), dim3(64), 72 * 1024, x.stream3, x, 0, x.gate_us);
         launch_chol(x, s, x.stream3, x.gate_us);
-        hipEventRecord(ej[2] = next_event(x), x.stream3);
+        HIPNOTE(hipEventRecord(ej[2] = next_event(x), x.stream3));
     } else if (overlap) {
         hipEvent_t ef = next_event(x);
-        hipEventRecord(ef, x.stream);
-        hipStreamWaitEvent(x.stream2, ef, 0);
+        HIPNOTE(hipEventRecord(ef, x.stream));
+        HIPNOTE(hipStreamWaitEvent(x.stream2, ef, 0));
         launch_gram(x, s, sb, timed);
         launch_chol(x, s, sb);
-        hipEventRecord(ej[0] = next_event(x), x.stream2);
+        HIPNOTE(hipEventRecord(ej[0] = next_event(x), x.stream2));
     }
     if (prev_tail) launch_tail(x, s - 1, 1023, 0);
     launch_node(x, s, 3);
     launch_xpass(x, s, 3);
     launch_rhs(x, s);
-    if (overlap) { for (hipEvent_t e : ej) if (e) hipStreamWaitEvent(x.stream, e, 0); }
+    if (overlap) { for (hipEvent_t e : ej) if (e) HIPNOTE(hipStreamWaitEvent(x.stream, e, 0)); }
     else { launch_gram(x, s, sb, timed); launch_chol(x, s, sb); }
     launch_solve(x);
     launch_backproj(x, s, 7);
@@ -942,7 +957,7 @@ static int run_exec(bnr_exec &x, int first_index, int count, int prog_freq, bnr_
         if (rc) return rc;
     }
     if (count > 0) launch_tail(x, -1, 1023, 0);                        // scalar tail of the last sweep
-    if (x.profiling) hipEventRecord(r1, x.stream);
+    if (x.profiling) HIPNOTE(hipEventRecord(r1, x.stream));
     // the members' event counters: one gather + one copy for the whole run call (read by the caller after the sync below)
     hipLaunchKernelGGL(k_gather_counters, dim3(x.nb), dim3(16), 0, x.stream, (const bnr_dev *)x.cds, x.status_dev);
     HIPCHK(hipMemcpyAsync(x.status_pin, x.status_dev, sizeof(long long) * 16 * x.nb, hipMemcpyDeviceToHost, x.stream));
@@ -951,10 +966,10 @@ static int run_exec(bnr_exec &x, int first_index, int count, int prog_freq, bnr_
     HIPCHK(hipStreamSynchronize(x.stream));
     if (x.profiling && count > 0) {
         float ms = 0;
-        hipEventElapsedTime(&ms, r0, r1);
+        HIPNOTE(hipEventElapsedTime(&ms, r0, r1));
         x.t_iter_us = 1e3 * ms / count; x.n_iter = count;
         x.t_gram_us = x.n_gram ? 1e3 * x.t_gram_acc / x.n_gram : 0;
-        hipEventDestroy(r0); hipEventDestroy(r1);
+        (void)hipEventDestroy(r0); hipEventDestroy(r1);
     }
     return BNR_OK;
 }
@@ -1007,7 +1022,7 @@ int bnr_group_create(bnr_chain *const *chains, int32_t nchains, bnr_group **out)
 int bnr_group_destroy(bnr_group *g)
 {
     if (!g) return BNR_OK;
-    hipSetDevice(g->x.device);
+    HIPNOTE(hipSetDevice(g->x.device));
     for (bnr_chain *c : g->m) c->group = nullptr;
     exec_free(g->x);
     delete g;
@@ -1088,13 +1103,30 @@ static int exec_last_timing(bnr_exec &x, int which, double *avg_us, int64_t *lau
 // latest state into the two hidden rows behind each table; the table, the iteration counter and the event counters are
 // untouched, the carried sums are marked stale (the next run call re-derives them as after a load).
 // Skipped silently for a member without a state yet (init_prior / run not called).
+static int ladder_sweeps(const bnr_exec &x)
+{
+    int K = 0;
+    for (int k = x.graph_k; k >= 1; k /= 2) K += k;
+    return K;
+}
+static int prime_graphs_inner(bnr_exec &x, const std::vector<bnr_chain *> &members, std::vector<std::vector<long long>> &saved);
 static int prime_graphs(bnr_exec &x, const std::vector<bnr_chain *> &members)
+{
+    // whatever happens in there, the members' event counters are put back as they were (the discarded sweeps must not count)
+    std::vector<std::vector<long long>> saved;
+    int rc = prime_graphs_inner(x, members, saved);
+    for (size_t i = 0; i < saved.size() && i < members.size(); ++i) {
+        if (hipMemcpy(members[i]->d.counters, saved[i].data(), sizeof(long long) * 16, hipMemcpyHostToDevice) != hipSuccess && !rc) rc = fail(BNR_ERR_HIP, "restoring the event counters failed");
+        members[i]->carried_row = -1;
+    }
+    return rc;
+}
+static int prime_graphs_inner(bnr_exec &x, const std::vector<bnr_chain *> &members, std::vector<std::vector<long long>> &saved)
 {
     if (x.ladder.empty() || x.profiling || !x.use_graph) return BNR_OK;
     int K = 0;
     for (const auto &r : x.ladder) K += r.k;
     for (bnr_chain *c : members) if (c->iter < 1 || c->next_row < 2 || c->next_row - 2 >= c->d.tot || c->pending) return BNR_OK;
-    std::vector<std::vector<long long>> saved;
     for (bnr_chain *c : members) {
         int rc = ensure_plan(c, K + 1);
         if (rc) return rc;
@@ -1117,10 +1149,6 @@ static int prime_graphs(bnr_exec &x, const std::vector<bnr_chain *> &members)
     hipLaunchKernelGGL(k_setbase, dim3(x.nb), dim3(1), 0, x.stream, (const bnr_dev *)x.cds, 1);
     for (const auto &r : x.ladder) HIPCHK(hipGraphLaunch(r.gexec, x.stream));
     HIPCHK(hipStreamSynchronize(x.stream));
-    for (size_t i = 0; i < members.size(); ++i) {
-        HIPCHK(hipMemcpy(members[i]->d.counters, saved[i].data(), sizeof(long long) * 16, hipMemcpyHostToDevice));
-        members[i]->carried_row = -1;
-    }
     return check_launch("prime");
 }
 
@@ -1130,7 +1158,9 @@ int bnr_group_prepare(bnr_group *g)
     if (g->m.empty()) return fail(BNR_ERR_BAD_ARG, "the group was dissolved (one of its chains was destroyed)");
     HIPCHK(hipSetDevice(g->x.device));
     for (bnr_chain *c : g->m) if (c->d.tot != g->m[0]->d.tot) return fail(BNR_ERR_BAD_ARG, "members of a group must have tables of equal length");
-    int rc = exec_prepare(g->x);
+    int rc;
+    for (bnr_chain *c : g->m) { rc = ensure_plan(c, ladder_sweeps(g->x) + 1); if (rc) return rc; }   // BEFORE the capture: a regrown plan drops graphs
+    rc = exec_prepare(g->x);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(g->x.stream));
     rc = check_launch("prepare");
@@ -1142,7 +1172,9 @@ int bnr_chain_prepare(bnr_chain *c)
     if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
     if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");
     HIPCHK(hipSetDevice(c->device));
-    int rc = exec_prepare(c->x);
+    int rc = ensure_plan(c, ladder_sweeps(c->x) + 1);                 // BEFORE the capture: a regrown plan drops graphs
+    if (rc) return rc;
+    rc = exec_prepare(c->x);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->x.stream));
     rc = check_launch("prepare");
@@ -1365,7 +1397,7 @@ static int table_io(bnr_chain *c, bool fetch, int first_row, int last_row, int h
             if (!rc && hipStreamSynchronize(c->x.stream) != hipSuccess) rc = fail(BNR_ERR_HIP, "table copy sync failed");
         }
     }
-    hipFree(stage);
+    (void)hipFree(stage);
     if (!fetch) c->carried_row = -1;
     return rc ? rc : check_launch("table_io");
 }
@@ -1419,9 +1451,10 @@ int bnr_chain_resize(bnr_chain *c, int32_t new_tot)
     if (rc) return rc;
     size_t keep = (size_t)std::min(new_tot, d.tot) * d.rowlen * sizeof(double);   // the hidden scratch row holds nothing between calls
     HIPCHK(hipMemcpy(nt, old, keep, hipMemcpyDeviceToDevice));
-    hipFree(old);
+    (void)hipFree(old);
     d.trace = nt; d.tot = new_tot;
     drop_graph(c->x);
+    if (c->group) drop_graph(c->group->x);             // a one-member group bakes the member's descriptor into its graphs as well
     return sync_dev(c);
 }
 
@@ -1439,7 +1472,7 @@ int bnr_chain_rhat_stats(bnr_chain *c, int32_t first_row, int32_t nsamp, double 
     hipLaunchKernelGGL(k_rhat_stats, dim3((np + 127) / 128), dim3(128), 0, c->x.stream, c->d, first_row - 1, nsamp, out);
     hipError_t e = hipMemcpyAsync(stats, out, sizeof(double) * 4 * np, hipMemcpyDeviceToHost, c->x.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->x.stream);
-    hipFree(out);
+    (void)hipFree(out);
     if (e != hipSuccess) return fail(BNR_ERR_HIP, std::string("rhat_stats: ") + hipGetErrorString(e));
     return check_launch("k_rhat_stats");
 }
@@ -1457,7 +1490,23 @@ struct bnr_comm {
     hipStream_t stream = nullptr;
     bnr_allgather_fn fn = nullptr;
     void *ctx = nullptr;
+    double *dsend = nullptr, *drecv = nullptr;   // RCCL: persistent device staging (send block, gathered block), grown on demand
+    size_t dcap = 0;                            // doubles per rank they hold
 };
+// device staging of an RCCL communicator for `count` doubles per rank
+static int comm_reserve(bnr_comm *c, size_t count)
+{
+    if (count <= c->dcap) return BNR_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->dsend) hipFree(c->dsend);
+    if (c->drecv) hipFree(c->drecv);
+    c->dsend = c->drecv = nullptr; c->dcap = 0;
+    const size_t cap = std::max<size_t>(count, 1024);
+    HIPCHK(hipMalloc((void **)&c->dsend, sizeof(double) * cap));
+    HIPCHK(hipMalloc((void **)&c->drecv, sizeof(double) * cap * (size_t)c->world));
+    c->dcap = cap;
+    return BNR_OK;
+}
 namespace {
 struct rccl_api {
     void *dl = nullptr;
@@ -1529,7 +1578,7 @@ int bnr_comm_create_rccl(const bnr_unique_id *id, int32_t rank, int32_t world, i
     c->rank = rank; c->world = world; c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(BNR_ERR_HIP, "hipStreamCreate failed"); }
     int e = g_rccl.CommInitRank(&c->nccl, world, *id, rank);
-    if (e) { hipStreamDestroy(c->stream); delete c; return rccl_fail("ncclCommInitRank", e); }
+    if (e) { (void)hipStreamDestroy(c->stream); delete c; return rccl_fail("ncclCommInitRank", e); }
     *out = c;
     return BNR_OK;
 }
@@ -1544,8 +1593,10 @@ int bnr_comm_create_callback(int32_t rank, int32_t world, bnr_allgather_fn fn, v
 int bnr_comm_destroy(bnr_comm *c)
 {
     if (!c) return BNR_OK;
-    if (c->nccl) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); g_rccl.CommDestroy(c->nccl); }
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->nccl) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); g_rccl.CommDestroy(c->nccl); }
+    if (c->dsend) hipFree(c->dsend);
+    if (c->drecv) hipFree(c->drecv);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return BNR_OK;
 }
@@ -1553,31 +1604,22 @@ int bnr_comm_destroy(bnr_comm *c)
 int bnr_comm_allgather(bnr_comm *c, const double *send, double *recv, int64_t count)
 {
     if (!send || !recv || count < 0) return fail(BNR_ERR_BAD_ARG, "bad all-gather arguments");
-    if (!c || c->world == 1) { memcpy(recv, send, sizeof(double) * (size_t)count); return BNR_OK; }
+    if (!c) { memcpy(recv, send, sizeof(double) * (size_t)count); return BNR_OK; }       // no communicator: one rank
     if (c->fn) {
         int e = c->fn(c->ctx, send, recv, count);
         return e ? fail(BNR_ERR_HIP, "the host's all-gather callback reported " + std::to_string(e)) : BNR_OK;
     }
+    // RCCL, also with ONE rank (the collective is then a device copy inside RCCL, but it is the same call path as with eight)
     HIPCHK(hipSetDevice(c->device));
-    double *ds = nullptr, *dr = nullptr;
-    HIPCHK(hipMalloc((void **)&ds, sizeof(double) * (size_t)std::max<int64_t>(count, 1)));
-    if (hipMalloc((void **)&dr, sizeof(double) * (size_t)std::max<int64_t>(count, 1) * c->world) != hipSuccess) { hipFree(ds); return fail(BNR_ERR_HIP, "hipMalloc failed"); }
-    int rc = BNR_OK;
-    hipError_t he = hipMemcpyAsync(ds, send, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream);
-    if (he == hipSuccess) {
-        int e = g_rccl.AllGather(ds, dr, (size_t)count, 8 /* ncclFloat64 */, c->nccl, c->stream);
-        if (e) rc = rccl_fail("ncclAllGather", e);
-    }
-    if (!rc && he == hipSuccess) he = hipMemcpyAsync(recv, dr, sizeof(double) * (size_t)count * c->world, hipMemcpyDeviceToHost, c->stream);
-    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-    hipFree(ds); hipFree(dr);
-    if (!rc && he != hipSuccess) rc = fail(BNR_ERR_HIP, std::string("all-gather copies: ") + hipGetErrorString(he));
-    return rc;
+    int rc = comm_reserve(c, (size_t)count);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->dsend, send, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    int e = g_rccl.AllGather(c->dsend, c->drecv, (size_t)count, 8 /* ncclFloat64 */, c->nccl, c->stream);
+    if (e) return rccl_fail("ncclAllGather", e);
+    HIPCHK(hipMemcpyAsync(recv, c->drecv, sizeof(double) * (size_t)count * c->world, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BNR_OK;
 }
-
-// rhat() over ALL chains of a fit (convergence.jl:4-65 + return_psrf_VOI, gibbs.jl:771-789): chains c = 1..nchains_total live
-// round-robin on the ranks ((c - 1) % world == rank, in increasing c: the reference's pmap order).  Every local chain reduces
-// its window on the device, the 4 (q + V)-double messages are all-gathered, every rank finishes the same Rhat.
 int bnr_rhat(bnr_chain *const *chains, int32_t nchains_local, int32_t nchains_total, bnr_comm *comm, int32_t burn, int32_t nsamp,
              double *rhat_xi, double *rhat_gamma)
 {
@@ -1599,14 +1641,41 @@ int bnr_rhat(bnr_chain *const *chains, int32_t nchains_local, int32_t nchains_to
     if (q <= 0 || V <= 0) return fail(BNR_ERR_BAD_ARG, "no rank holds a chain");
     const int np = q + V;
     const size_t width = (size_t)4 * np;
-    std::vector<double> send(width * per_rank, 0.0), recv(width * per_rank * world);
-    for (int i = 0; i < nchains_local; ++i) {
+    std::vector<double> recv(width * per_rank * world);
+    for (int i = 0; i < nchains_local; ++i)
         if (!chains[i] || chains[i]->d.q != q || chains[i]->d.V != V) return fail(BNR_ERR_BAD_ARG, "chains of one fit must have equal V");
-        int rc = bnr_chain_rhat_stats(chains[i], burn + 1, nsamp, send.data() + width * i);
+    if (comm && comm->nccl) {
+        // RCCL: the per-chain messages never leave the device before the collective -- k_rhat_stats writes each chain's block straight
+        // into the communicator's send buffer, ncclAllGather moves them GPU to GPU, ONE copy brings the gathered block to the host
+        HIPCHK(hipSetDevice(comm->device));
+        int rc = comm_reserve(comm, width * per_rank);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(comm->dsend, 0, sizeof(double) * width * per_rank, comm->stream));
+        HIPCHK(hipStreamSynchronize(comm->stream));
+        for (int i = 0; i < nchains_local; ++i) {
+            bnr_chain *c = chains[i];
+            if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");
+            if (c->device != comm->device) return fail(BNR_ERR_BAD_ARG, "the chains of this rank must live on the communicator's device");
+            if (nsamp < 4 || burn + nsamp > c->d.tot || burn < 0) return fail(BNR_ERR_BAD_ARG, "row window outside the table or nsamp < 4");
+            hipLaunchKernelGGL(k_rhat_stats, dim3((np + 127) / 128), dim3(128), 0, c->x.stream, c->d, burn, nsamp, comm->dsend + width * i);
+            HIPCHK(hipStreamSynchronize(c->x.stream));
+        }
+        rc = check_launch("k_rhat_stats");
+        if (rc) return rc;
+        int e = g_rccl.AllGather(comm->dsend, comm->drecv, width * per_rank, 8 /* ncclFloat64 */, comm->nccl, comm->stream);
+        if (e) return rccl_fail("ncclAllGather", e);
+        HIPCHK(hipMemcpyAsync(recv.data(), comm->drecv, sizeof(double) * recv.size(), hipMemcpyDeviceToHost, comm->stream));
+        HIPCHK(hipStreamSynchronize(comm->stream));
+    } else {
+        std::vector<double> send(width * per_rank, 0.0);
+        for (int i = 0; i < nchains_local; ++i) {
+            int rc = bnr_chain_rhat_stats(chains[i], burn + 1, nsamp, send.data() + width * i);
+            if (rc) return rc;
+        }
+        int rc = bnr_comm_allgather(comm, send.data(), recv.data(), (int64_t)send.size());
         if (rc) return rc;
     }
-    int rc = bnr_comm_allgather(comm, send.data(), recv.data(), (int64_t)send.size());
-    if (rc) return rc;
+    int rc;
     std::vector<double> stats(width * nchains_total), rh(np);
     for (int c = 1; c <= nchains_total; ++c)
         memcpy(stats.data() + width * (c - 1), recv.data() + width * ((size_t)((c - 1) % world) * per_rank + (c - 1) / world), sizeof(double) * width);
@@ -1639,7 +1708,7 @@ int bnr_chain_summary(bnr_chain *c, int32_t first_row, int32_t nsamp, int32_t k_
     std::vector<double> host(3 * (size_t)np);
     hipError_t e = hipMemcpyAsync(host.data(), out, sizeof(double) * host.size(), hipMemcpyDeviceToHost, c->x.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->x.stream);
-    hipFree(buf); hipFree(out);
+    (void)hipFree(buf); hipFree(out);
     if (e != hipSuccess) return fail(BNR_ERR_HIP, std::string("summary: ") + hipGetErrorString(e));
     memcpy(mean_gamma, host.data(), sizeof(double) * d.q);
     memcpy(prob_xi, host.data() + d.q, sizeof(double) * d.V);
@@ -1669,7 +1738,7 @@ int bnr_chain_ess_stats(bnr_chain *c, int32_t first_row, int32_t nsamp, int32_t 
     hipLaunchKernelGGL(k_acov, dim3(np, 2), dim3(256), 0, c->x.stream, (const double *)buf, nsamp, np, max_lag, out);
     hipError_t e = hipMemcpyAsync(stats, out, sizeof(double) * width, hipMemcpyDeviceToHost, c->x.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->x.stream);
-    hipFree(buf); hipFree(out);
+    (void)hipFree(buf); hipFree(out);
     if (e != hipSuccess) return fail(BNR_ERR_HIP, std::string("ess_stats: ") + hipGetErrorString(e));
     return check_launch("k_acov");
 }
@@ -1800,14 +1869,14 @@ int bnr_chain_debug_time_gram(bnr_chain *c, int32_t reps, double *avg_us)
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     for (int w = 0; w < 3; ++w) launch_gram_only(c);
-    hipEventRecord(e0, c->x.stream);
+    HIPNOTE(hipEventRecord(e0, c->x.stream));
     for (int r = 0; r < reps; ++r) launch_gram_only(c);
-    hipEventRecord(e1, c->x.stream);
+    HIPNOTE(hipEventRecord(e1, c->x.stream));
     HIPCHK(hipMemsetAsync(c->d.gprog, 0, sizeof(unsigned int) * (c->d.ntile + 1), c->x.stream));   // these launches were not consumed by a factorization
     HIPCHK(hipStreamSynchronize(c->x.stream));
     float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    HIPNOTE(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); hipEventDestroy(e1);
     *avg_us = 1e3 * ms / reps;
     c->carried_row = -1;
     return check_launch("debug_time_gram");

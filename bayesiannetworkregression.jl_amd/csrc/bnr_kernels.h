@@ -585,13 +585,15 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
     bnr_gram_count(cd, tj);
 }
 
-// k_gram8: the same Gram, the same task map, the same summation order per element (bitwise the same partial tiles) -- for
-// EIGHT wavefronts per SIMD.  The issue rate of v_mfma_f64_16x16x4_f64 on a SIMD depends on how many waves feed it, not on how
-// many independent accumulators a wave has (profiles/round1_mfma_f64_peak.txt: 1 wave 139-180 cycles per MFMA whatever NACC,
-// 2 waves 103, 4 waves 92, 8 waves 71; 64 = spec).  Eight waves per SIMD = four 512-thread workgroups per CU: at most 64 VGPRs per
-// wave and 40 KiB of LDS per workgroup.  Hence batches of 8 columns (half the staging registers and half the LDS image of k_gram's
-// 16: 2 K-groups x 2 buffers x [I | J] x 8 x 64 doubles = 32 KiB; a barrier per 8 MFMAs of a wave) and a K-group reduction that needs
-// one tile of LDS instead of two (K-group 1 parks its tile, K-group 0 adds its registers and stores).
+// k_gram8: the same Gram, the same task map, the same summation order per element (bitwise the same partial tiles) -- for SIX
+// wavefronts per SIMD.  The issue rate of v_mfma_f64_16x16x4_f64 on a SIMD depends on how many waves feed it, not on how many
+// independent accumulators a wave has (profiles/round1_mfma_f64_peak.txt: 1 wave 139-180 cycles per MFMA whatever NACC, 2 waves 103,
+// 4 waves 92, 8 waves 71; 64 = spec).  Three 512-thread workgroups per CU = 6 waves per SIMD: __launch_bounds__(512, 6) -- the second
+// argument is the minimum number of WAVES PER SIMD, not of blocks per CU -- caps the kernel at 80 VGPRs (74 used, no spills), and
+// batches of 8 columns keep a workgroup at 32 KiB of LDS (half the staging registers and half the image of k_gram's 16:
+// 2 K-groups x 2 buffers x [I | J] x 8 x 64 doubles; a barrier per 8 MFMAs of a wave), with a K-group reduction that needs one tile
+// of LDS instead of two (K-group 1 parks its tile, K-group 0 adds its registers and stores).  Eight waves per SIMD (64 VGPRs through
+// buffer descriptors) brought nothing more (profiles/round2_experiments_notes.txt D).
 // a partial-tile element goes to memory either as a plain store (consumed after the kernel boundary) or written through to the
 // agent's coherence point (sc1), for a consumer that runs beside this kernel on another XCD
 template <bool WT>

@@ -1,4 +1,7 @@
 # BNRHip.jl -- thin Julia shim over libbnr_hip.so (include/bnr_hip.h).
+# SPDX-License-Identifier: GPL-2.0-or-later.  The schedule arithmetic of `generate_samples!` below (num2move, first_index, the
+# messages) restates BayesianNetworkRegression.jl src/gibbs.jl:955-1013 (GPL-2.0, Ozminkowski & Solis-Lemus) so that this
+# module is a drop-in for that function; everything else is `ccall` glue written for this repository.
 #
 # Drop-in for the Gibbs hot path of BayesianNetworkRegression.jl: `generate_samples!` with the reference's argument meaning
 # (src/gibbs.jl:897-1020, including the PSRF-driven top-up rounds) returning the reference's own
@@ -107,9 +110,15 @@ function run!(x::Union{Group,Chain}, first_index, nburn, total, purge_burn; prog
     nxt = Ref{Int32}(0)
     TICK[] = tick
     cb = tick === nothing ? C_NULL : @cfunction(tick_trampoline, Cvoid, (Ptr{Cvoid}, Int64))
-    f = x isa Group ? :bnr_group_run : :bnr_chain_run
-    check(ccall((f, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}),
-        x.h, first_index, nburn, total, isnothing(purge_burn) ? 0 : purge_burn, tick === nothing ? 0 : prog_freq, cb, C_NULL, nxt))
+    pb, pf = Int32(isnothing(purge_burn) ? 0 : purge_burn), Int32(tick === nothing ? 0 : prog_freq)
+    # (the (name, library) target of a ccall must be a constant expression: two literal calls, not a symbol chosen at run time)
+    if x isa Group
+        check(ccall((:bnr_group_run, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}),
+            x.h, first_index, nburn, total, pb, pf, cb, C_NULL, nxt))
+    else
+        check(ccall((:bnr_chain_run, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}),
+            x.h, first_index, nburn, total, pb, pf, cb, C_NULL, nxt))
+    end
     Int(nxt[])
 end
 prepare!(g::Group) = check(ccall((:bnr_group_prepare, LIB), Cint, (Ptr{Cvoid},), g.h))   # optional: captures the replayed graphs now

@@ -261,3 +261,38 @@ def test_rhat_exchange_two_ranks_gloo(tmp_path, num_chains):
     assert np.array_equal(r0, r1)
     ref = np.stack([np.random.default_rng(100 + c).random(36) for c in range(1, num_chains + 1)])
     assert np.allclose(r0, bnr_amd.rhat_from_stats(ref, 20))
+
+
+def test_chains_are_refused_when_a_foreign_hip_runtime_was_loaded_first(tmp_path):
+    """Load order: a process serves every libamdhip64 user from the first copy mapped.  With torch (which carries its own
+    ROCm runtime) imported BEFORE the library, chain creation is refused with a message that says so; the GPU-free entry points
+    stay usable; with the library loaded first everything is as usual."""
+    script = tmp_path / "order.py"
+    script.write_text(r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+first = sys.argv[1]
+if first == "torch":
+    import torch
+import bnr_amd
+from bnr_amd import _capi
+L = _capi.lib()
+assert L.bnr_abi_version() >= 1
+if first != "torch":
+    import torch
+print("FOREIGN" if _capi._foreign_hip else "OWN")
+assert _capi.rhat_from_stats(np.random.default_rng(1).random((2, 8)), 20).shape == (2,)       # GPU-free: always available
+X, y, _ = bnr_amd.make_synthetic(8, 3, 2, seed=1)
+try:
+    bnr_amd.Chain(X, y, 2, 4, 1, 1)
+    print("CREATED")
+except _capi.BnrError as e:
+    print("REFUSED" if "BEFORE importing torch" in str(e) else "OTHER: " + str(e))
+''' % ROOT)
+    out = subprocess.run([sys.executable, str(script), "torch"], capture_output=True, text=True, timeout=300).stdout.split()
+    has_foreign = out[0] == "FOREIGN"               # only if the torch wheel really ships a runtime of its own
+    if has_foreign:
+        assert out[1] == "REFUSED", out
+    out = subprocess.run([sys.executable, str(script), "lib"], capture_output=True, text=True, timeout=300).stdout.split()
+    assert out[0] == "OWN" and out[1] in ("CREATED", "OTHER:"), out      # OTHER: no GPU in this container (BNR_ERR_HIP from hipGetDeviceCount)
