@@ -862,6 +862,7 @@ static int status_of(const long long *cnt)
         snprintf(buf, sizeof buf, "Cholesky failed after the jitter ladder (node %lld, Psi %lld, M %lld, G+I %lld)", cnt[4], cnt[5], cnt[6], cnt[7]);
         return fail(BNR_ERR_CHOLESKY, buf);
     }
+    if (cnt[2] > 0) return fail(BNR_ERR_SAMPLER_CAP, "a rejection sampler stopped at its attempt cap (" + std::to_string(cnt[2]) + " draws): the values written are the samplers' fall-backs");
     return BNR_OK;
 }
 static int fetch_status(bnr_chain *c)

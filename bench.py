@@ -5,11 +5,12 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = one Gibbs sweep (gibbs_sample!, gibbs.jl:663-677) of every chain resident on the GPU.  Workload: synthetic
-n=500, V=100 (q=5050), R=7 (SURVEY.md 8d generator, seed 20240501), the 8 chains of BASELINE.json configs[2] on every
-GPU (they advance as one lockstep group: one launch per kernel for all of them), weak scaling: per-GPU work is fixed,
-chains are independent, no data-path collective; after the timed region the per-chain split-Rhat messages are
-all-gathered over RCCL (reported, not timed).  The same line also carries the latency-bound figure of configs[2]'s
-literal layout, ONE chain per GPU ("single_chain"), measured in the same process.
+n=500, V=100 (q=5050), R=7 (SURVEY.md 8d generator, seed 20240501), the 8 chains of BASELINE.json configs[2] IN ALL:
+chain c lives on rank (c-1) % N (the reference's pmap over chains, gibbs.jl:946-948), the 8/N chains of a GPU advance as one
+lockstep group (one launch per kernel for all of them; N = 8: one chain per GPU, configs[2]'s literal layout).  Chains are
+independent: no data-path collective; total work is fixed as N grows ("scaling": "strong").  After the timed region the
+per-chain split-Rhat messages are all-gathered over RCCL (reported, not timed).  Sub-records of the same line: at N = 1
+"single_chain" (one chain alone on the GPU, latency-bound), at N > 1 "weak_scaling" (8 chains on EVERY GPU).
 Inputs are resident in HBM when the timed region starts.  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -41,7 +42,7 @@ blas = bo.use_numpy_openblas(threads) if mode == 2 else None
 if mode == 2 and blas is None:
     mode = 1
 X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=seed)
-tot = 256
+tot = 4096                                # the time budget ends the run, not the table (<= ~70 iterations/s/chain)
 o = bo.Oracle(X, y, R, tot, seed, chain=chain, pdf_mode=0, cost_mode=mode)
 o.init_prior()
 o.gibbs_sample(1, 2)                      # warm-up (page faults, thread pool)
@@ -86,7 +87,7 @@ def cpu_baseline(n, V, R, seed, nchains, budget_s=15.0, mode=2):
         its += int(out[0]); rate += int(out[0]) / float(out[1]); threads += int(out[2]); used = int(out[3]); blas = tail.strip()
     how = ("Gram (dense 2n^2q dgemm) and LU solve by OpenBLAS: " + blas) if used == 2 else "plain-C loops of the oracle (OpenMP Gram, unblocked LU), no BLAS"
     return dict(value=rate, unit="Gibbs iterations/s (all chains)", cores=threads, kind="port",
-                sample="%d chains x ~%.0f s of the same n/V/R workload (%d iterations in all), one process per chain with %d "
+                sample="%d chains x %.0f s wall (budget) of the same n/V/R workload (%d iterations in all), one process per chain with %d "
                        "threads each; reference-cost mode: %s" % (nchains, budget_s, its, per, how))
 
 
@@ -111,7 +112,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
-    ap.add_argument("--chains-per-gpu", type=int, default=8)
+    ap.add_argument("--chains", type=int, default=8, help="chains of the fit in all (BASELINE configs[2]: 8), sharded round-robin over the ranks")
+    ap.add_argument("--chains-per-gpu", type=int, default=0, help="diagnostics: this many chains on EVERY GPU instead (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=20240501)
     ap.add_argument("--overlap", type=int, default=1, help="0: single-stream schedule (diagnostics)")
@@ -189,10 +191,14 @@ def main():
     n, V, R = cfg["n"], cfg["V"], cfg["R"]
     q = V * (V + 1) // 2
     X, y, _truth = bnr_amd.make_synthetic(n, V, R, seed=a.seed)
-    K, W, C = a.steps, a.warmup, a.chains_per_gpu
+    K, W = a.steps, a.warmup
+    total_chains = world * a.chains_per_gpu if a.chains_per_gpu > 0 else a.chains
     tot = W + K + min(K, 200) + 1
     chains = []
-    ids = [c for c in range(1, world * C + 1) if (c - 1) % world == rank]     # round-robin over ranks, as api.local_chain_ids
+    ids = [c for c in range(1, total_chains + 1) if (c - 1) % world == rank]  # round-robin over ranks, as api.local_chain_ids
+    if not ids:
+        raise SystemExit("bench.py: more ranks (%d) than chains (%d): rank %d would hold none" % (world, total_chains, rank))
+    C = len(ids)                                                  # chains resident on THIS GPU
     for cid in ids:                                               # chain c uses stream seed + c (gibbs.jl:928)
         ch = bnr_amd.Chain(X, y, R, tot, a.seed, cid, device=local_rank) if not chains else bnr_amd.Chain.like(chains[0], a.seed, cid, tot)
         ch.init_prior()
@@ -249,9 +255,10 @@ def main():
     gram_us, gram_n = runner.last_timing(1)
     counters = chains[0].counters()
 
-    # configs[2]'s literal layout, one chain per GPU: chain 1 of this rank alone (continues its table; latency-bound)
-    single = None
-    if C > 1:
+    # N = 1: one chain alone on the GPU (what every GPU does at N = 8; latency-bound).  N > 1: the weak-scaling figure, 8 chains on
+    # EVERY GPU as one lockstep group.  Both continue from chain 1's data in the same process; reported as sub-records.
+    single, weak = None, None
+    if C > 1 and world == 1:
         runner.close()
         runner = None
         Ks = min(K, 1000)
@@ -265,6 +272,29 @@ def main():
         dts = max_over_ranks(time.perf_counter() - t1)
         single = {"value": world * Ks / dts, "unit": "iterations/s", "chains_per_gpu": 1, "steps": Ks, "ms_per_step": 1e3 * dts / Ks}
         solo.close()
+    elif world > 1 and a.chains_per_gpu == 0:
+        if C > 1:
+            runner.close()
+        runner = None
+        Kw, Cw = min(K, 1000), 8
+        wch = [bnr_amd.Chain.like(chains[0], a.seed, 1000 + rank * Cw + i, Kw + 50) for i in range(Cw)]
+        for ch in wch:
+            ch.init_prior()
+        wg = bnr_amd.Group(wch)
+        wg.prepare()
+        wg.run(2, 49, 49)
+        device_sync()
+        dist.barrier()
+        t1 = time.perf_counter()
+        wg.run(50, Kw + 49, Kw + 49)
+        device_sync()
+        dist.barrier()
+        dtw = max_over_ranks(time.perf_counter() - t1)
+        weak = {"value": world * Cw * Kw / dtw, "unit": "iterations/s", "scaling": "weak", "chains_per_gpu": Cw, "chains_total": world * Cw,
+                "steps": Kw, "ms_per_step": 1e3 * dtw / Kw}
+        wg.close()
+        for ch in wch:
+            ch.close()
 
     # convergence check over all chains of the job (return_psrf_VOI, gibbs.jl:771-789): bnr_rhat -- device reduction per chain, ONE
     # all-gather of the 4 (q + V)-double messages on the library's RCCL communicator (ncclAllGather over xGMI), Rhat finished on
@@ -273,20 +303,19 @@ def main():
     nsamp = K
     rh = None
     if nsamp >= 4:                                               # split-Rhat needs two samples per half
-        rg, rx = _capi.rhat(chains, world * C, comm, W + 1, nsamp)
+        rg, rx = _capi.rhat(chains, total_chains, comm, W + 1, nsamp)
         rh = np.concatenate([rg, rx])
     # effective sample size of the timed window over all chains (an addition to the reference's Rhat; same exchange pattern)
     ess = None
     if nsamp >= 64:
         Lag = min(250, nsamp // 4)
         local_e = {cid: ch.ess_stats(W + 2, nsamp, Lag) for cid, ch in zip(ids, chains)}
-        stats_e = bnr_amd.allgather_stats(local_e, world * C, comm) if comm is not None else np.stack([local_e[c] for c in sorted(local_e)])
+        stats_e = bnr_amd.allgather_stats(local_e, total_chains, comm) if comm is not None else np.stack([local_e[c] for c in sorted(local_e)])
         ess = bnr_amd.ess_from_stats(stats_e, nsamp, Lag)
     if comm is not None:
         comm.close()
 
     if rank == 0:
-        total_chains = world * C
         value = total_chains * K / dt
         flops_gram = float(n) * n * q * C                         # algorithmic: symmetric X diag(S) X'  per chain of the launch
         traffic = None                                            # HBM bytes per k_gram launch from the PMC passes (tools/pmc_gram2.sh)
@@ -300,11 +329,11 @@ def main():
         out = {
             "metric": "Gibbs iterations/sec (all chains)", "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic n=%d V=%d (q=%d) R=%d, %d chain(s) per GPU, %d chains total" % (n, V, q, R, C, total_chains)
-                                   + ("" if world == 1 else " (weak scaling: every GPU runs the %d chains of BASELINE configs[2] as one lockstep group; configs[2]'s "
-                                      "literal layout, ONE chain per GPU = %d chains on %d GPUs, is the single_chain record of this line)" % (C, world, world)),
-                       "chains_per_gpu": C, "seed": a.seed},
+            "scaling": "weak" if (a.chains_per_gpu > 0 or world == 1) else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic n=%d V=%d (q=%d) R=%d, %d chains total, %s per GPU" % (n, V, q, R, total_chains, C if total_chains % world == 0 else "%d or %d" % (total_chains // world, total_chains // world + 1))
+                                   + ("" if world == 1 else " (BASELINE configs[2]: the %d chains of the fit sharded round-robin over %d GPUs, chain c on rank (c-1) %% %d; "
+                                      "the chains of a GPU advance as one lockstep group)" % (total_chains, world, world)),
+                       "chains_total": total_chains, "chains_per_gpu": C, "seed": a.seed},
             "timed_region": {"sweeps_replayed_from_graphs": int(replayed_sweeps), "sweeps_launched_eagerly": int(eager_sweeps)},
             "roofline": {"bound": "mfma", "kernel": "k_gram8 / k_gram (X diag(S) X', v_mfma_f64_16x16x4_f64)", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
@@ -315,14 +344,16 @@ def main():
                          "peak_measured_microbench": 70.0},
             "max_rhat_gamma": None if rh is None else float(np.nanmax(rh[:q])), "max_rhat_xi": None if rh is None else float(np.nanmax(rh[q:])),
             "ess_gamma": None if ess is None else {"min": float(np.nanmin(ess[:q])), "median": float(np.nanmedian(ess[:q])),
-                                                   "draws": int(nsamp * world * C), "min_per_second": float(np.nanmin(ess[:q]) / dt)},
+                                                   "draws": int(nsamp * total_chains), "min_per_second": float(np.nanmin(ess[:q]) / dt)},
             "counters": counters, "rhat_exchange": exchange,
         }
         if single is not None:
             out["single_chain"] = single
+        if weak is not None:
+            out["weak_scaling"] = weak
         if not a.no_cpu_baseline and world == 1:            # the host-core baseline is taken at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(n, V, R, a.seed, C, 15.0, 2)
-            out["cpu_baseline_no_blas"] = cpu_baseline(n, V, R, a.seed, C, 6.0, 1)
+            out["cpu_baseline"] = cpu_baseline(n, V, R, a.seed, total_chains, 15.0, 2)
+            out["cpu_baseline_no_blas"] = cpu_baseline(n, V, R, a.seed, total_chains, 6.0, 1)
         print(json.dumps(out))
     for ch in chains:
         ch.close()

@@ -955,6 +955,182 @@ def test_gram_kernels_write_the_same_tiles(gpu):
             assert np.array_equal(tabs[16][0][k], tabs[16][1][k]), ("group vs alone", n, V, R, k)
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# The reference's numerical failure paths, EXECUTED on the device (not only asserted to be absent): crafted rows are loaded with
+# bnr_chain_load, one update_*! hook runs on them, and the result, the event counters and the status word are the oracle's.
+# Exact arithmetic is used to make the branch taken independent of rounding: powers of two, all-ones loadings.
+def _edge_pair(V, R, hyper=None, n=12, seed=5):
+    X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=77)
+    ch, o = pair(X, y, R, 3, seed, **(hyper or {}))
+    ch.init_prior()
+    o.init_prior()
+    return ch, o
+
+
+def _oracle_counts(o):
+    return int(o.o.jitter_events), int(o.o.nan_w_events), int(o.o.status)
+
+
+def test_device_runs_the_jitter_ladder_of_the_node_update(gpu):
+    """gibbs.jl:322-347: Sigma^-1 = U'H^-1U/tau2 + inv(M) fails its Cholesky, + 1e-5 on the diagonal passes.  u_v = (1,1), lambda = (1,1),
+    S = 1, tau2 = 1, V = 17, M = 2^60 I: Sigma^-1 = 16 [[1,1],[1,1]] + 2^-60 I = 16 [[1,1],[1,1]] exactly (singular: second pivot
+    16 - 4^2 = 0), and with the first rung of the ladder the second pivot is 2e-5.  Every node takes the rung once."""
+    V, R = 17, 2
+    ch, o = _edge_pair(V, R)
+    t = o.t
+    t["u"][0] = 1.0; t["lam"][0] = 1.0; t["S"][0] = 1.0; t["gamma"][0] = 0.5; t["xi"][0] = 1.0; t["Delta"][0] = 0.5
+    t["M"][0] = np.eye(R) * 2.0 ** 60
+    t["tau2"][1] = 1.0
+    ch.load(t, 1, 2)
+    ch.update("u_xi", 2, 2)
+    o.update("u_xi", 1, 2)
+    jit, nanw, status = _oracle_counts(o)
+    c = ch.counters()
+    assert jit == V and status == 0 and c["jitter"] == V and c["chol_fail"] == 0 and c["nan_w"] == nanw == 0
+    g = ch.fetch(2, 2)
+    assert np.array_equal(g["xi"][0], t["xi"][1])
+    assert np.allclose(g["u"][0], t["u"][1], rtol=RTOL, atol=ATOL) and np.isfinite(g["u"][0]).all()
+    ch.close()
+
+
+def test_device_reports_a_cholesky_that_fails_after_the_whole_ladder(gpu):
+    """The same singular Sigma^-1 at a scale where 1e-5 + 4e-5 vanish in rounding (tau2 = 2^-44: 2^48 [[1,1],[1,1]], square root 2^24 exact, ulp 0.06): both rungs
+    fail, the reference rethrows (gibbs.jl:341-346) = status 3 here and in the oracle, with the node update named as the place."""
+    V, R = 17, 2
+    ch, o = _edge_pair(V, R)
+    t = o.t
+    t["u"][0] = 1.0; t["lam"][0] = 1.0; t["S"][0] = 1.0; t["gamma"][0] = 0.5; t["xi"][0] = 1.0; t["Delta"][0] = 0.5
+    t["M"][0] = np.eye(R) * 2.0 ** 60
+    t["tau2"][1] = 2.0 ** -44
+    ch.load(t, 1, 2)
+    with pytest.raises(bnr_amd.BnrError) as e:
+        ch.update("u_xi", 2, 2)
+    o.update("u_xi", 1, 2)
+    assert e.value.code == 3 == o.status and "node" in str(e.value)
+    c = ch.counters()
+    assert c["jitter"] >= 1 and c["chol_fail"] >= 1 and c["where"][0] >= 1 and o.o.jitter_events >= 1
+    ch.close()
+
+
+def test_device_flips_the_coin_when_the_node_weight_is_nan(gpu):
+    """gibbs.jl:353-360, 392-400: a weight that is NaN -- here through gamma = +Inf on the edge (5,2): c = U'H^-1 gamma is Inf, the two
+    substitutions turn it into NaN -- makes xi a fair coin from the XI draw site.  Nodes 2 and 5 take that branch (counted), their xi
+    equal the oracle's coin, their u is NaN in both (xi (mu_t + z) with mu_t = NaN); every other node is untouched by it."""
+    V, R = 9, 2
+    ch, o = _edge_pair(V, R, seed=11)
+    t = o.t
+    from bnr_amd import _capi
+    e52 = _capi.lib().bnr_host_edge_index(V, 5, 2)
+    t["gamma"][0, e52, 0] = np.inf
+    t["tau2"][1] = 0.7
+    ch.load(t, 1, 2)
+    ch.update("u_xi", 2, 2)
+    o.update("u_xi", 1, 2)
+    jit, nanw, status = _oracle_counts(o)
+    c = ch.counters()
+    assert nanw == 2 == c["nan_w"] and status == 0 and c["chol_fail"] == 0
+    g = ch.fetch(2, 2)
+    assert np.array_equal(g["xi"][0], t["xi"][1])
+    assert np.isnan(g["u"][0][:, [2, 5]]).all() and np.isnan(t["u"][1][:, [2, 5]]).all()
+    rest = [v for v in range(V) if v not in (2, 5)]
+    assert np.allclose(g["u"][0][:, rest], t["u"][1][:, rest], rtol=RTOL, atol=ATOL) and np.isfinite(g["u"][0][:, rest]).all()
+    ch.close()
+
+
+def test_device_runs_the_retry_of_update_M(gpu):
+    """gibbs.jl:529-543: Psi = I + sum u_v u_v' loses its identity in rounding when every u_v = (2^30, 2^30) (V 2^60 >> 2^53): Psi is an exactly
+    singular 2 x 2 matrix, the first Cholesky fails, + 1e-5 vanishes as well, the retry fails: jitter counted once, status 3, Psi named."""
+    V, R = 16, 2
+    ch, o = _edge_pair(V, R)
+    t = o.t
+    t["u"][1] = 2.0 ** 30
+    t["xi"][1] = 1.0
+    ch.load(t, 1, 2)
+    with pytest.raises(bnr_amd.BnrError) as e:
+        ch.update("M", 2, 2)
+    o.update("M", 1, 2)
+    c = ch.counters()
+    assert e.value.code == 3 == o.status and "Psi 1" in str(e.value)
+    assert c["jitter"] == 1 == o.o.jitter_events and c["chol_fail"] == 1 and c["where"][1] == 1
+    ch.close()
+
+
+@pytest.mark.parametrize("which", ["chi", "psi"])
+def test_device_takes_the_degenerate_gig_branches(gpu, which):
+    """gig.jl:15-26: chi < 10 eps (gamma == W on every edge: the draw is Gamma(1/2, scale 2/psi ... as the reference writes it) and
+    psi < 10 eps (theta = 1e-300: inverse-Gamma-type branch) -- S of the whole row through the device's update_D! equals the oracle's,
+    whose branch counters say which branch every edge took."""
+    V, R = 7, 2
+    ch, o = _edge_pair(V, R, seed=3)
+    t = o.t
+    q = V * (V + 1) // 2
+    for k in ("u", "lam", "tau2", "gamma", "xi"):
+        t[k][1] = t[k][0]                                    # row 2 carries the state update_D! reads (gamma, u of the row; lambda, theta of row 1)
+    if which == "chi":
+        W = o.compute_W(1, 0)                                # W(u of row 2, lambda of row 1)
+        t["gamma"][1, :, 0] = W
+    else:
+        t["theta"][0] = 1e-300
+    ch.load(t, 1, 2)
+    before = np.array(o.o.gig_branch[:])
+    ch.update("D", 2, 2)
+    o.update("D", 1, 2)
+    took = np.array(o.o.gig_branch[:]) - before
+    assert took.sum() == q and took[3 if which == "chi" else 4] == q, took      # every edge through the degenerate branch in question
+    g = ch.fetch(2, 2)
+    assert np.isfinite(g["S"][0]).all() and (g["S"][0] > 0).all()
+    assert np.allclose(g["S"][0], t["S"][1], rtol=RTOL, atol=0.0)
+    c = ch.counters()
+    assert c["sampler_cap"] == 0 and c["chol_fail"] == 0
+    ch.close()
+
+
+def test_device_reports_the_sampler_cap(gpu):
+    """A rejection sampler that never accepts (Gamma with shape NaN: zeta = NaN in update_theta!) stops at the attempt cap on the device as
+    in the oracle: status 4 (BNR_ERR_SAMPLER_CAP), counted."""
+    V, R = 5, 2
+    ch, o = _edge_pair(V, R, hyper=dict(zeta=float("nan")))
+    for k in ("u", "lam", "tau2", "gamma", "xi", "S"):
+        o.t[k][1] = o.t[k][0]
+    ch.load(o.t, 1, 2)
+    with pytest.raises(bnr_amd.BnrError) as e:
+        ch.update("theta", 2, 2)
+    o.update("theta", 1, 2)
+    assert e.value.code == 4 == o.status
+    assert ch.counters()["sampler_cap"] >= 1
+    ch.close()
+
+
+def test_post_burn_in_rows_match_the_oracle_at_config3(gpu):
+    """Full-size parity AFTER burn-in (most xi = 0, S small, the Gram well conditioned -- another regime than the rows right after the
+    prior draw): the 8 chains of BASELINE configs[2] run 2 000 sweeps as one lockstep group on the GPU, then the oracle continues from
+    the last row of chain 1 (same table, same iteration counter) for 3 rows, and the GPU's next 3 rows equal them (RTOL 1e-6)."""
+    n, V, R, tot = 500, 100, 7, 2004
+    X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=20240501)
+    chains = [bnr_amd.Chain(X, y, R, tot, 20240501, 1)]
+    chains += [bnr_amd.Chain.like(chains[0], 20240501, c, tot) for c in range(2, 9)]
+    for c in chains:
+        c.init_prior()
+    g = bnr_amd.Group(chains)
+    g.run(2, tot, 2001)
+    last = chains[0].fetch(2001, 2001)
+    assert (np.abs(last["xi"][0]) < 0.5).mean() > 0.3                # a post-burn-in state: a good share of the nodes switched off
+    table = bo.new_table(4, V, R)
+    for k in bo.COLUMNS:
+        table[k][0] = last[k][0]
+    o = bo.Oracle(X, y, R, 4, 20240501, chain=1, pdf_mode=1, table=table)
+    o.iter = 2001
+    g.run(2002, tot, tot)
+    o.run(2, 4, 4)
+    got = chains[0].fetch(2001, 2004)
+    assert_tables_close(got, o.t, what="config 3, rows 2002-2004 of chain 1")
+    cnt = chains[0].counters()
+    assert cnt["chol_fail"] == 0 and cnt["sampler_cap"] == 0
+    g.close()
+    for c in chains:
+        c.close()
+
+
 def test_factorization_and_schedule_variants_are_bitwise_equal(gpu):
     """The opt-in variants of round 3 -- the left-looking factorization k_chol_ll (K-split partials summed on the first touch, no
     k_gram_reduce), the persistent Gram k_gram8p (tasks from per-XCD queues, keeps off the reserved compute units) and the

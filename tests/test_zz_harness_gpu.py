@@ -53,25 +53,31 @@ def _run_bench_ranks(tmp_path, nranks, extra, env_extra):
 
 def test_bench_multi_rank_path_rehearsal(gpu, tmp_path):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed with two ranks on
-    this one GPU (BNR_BENCH_ONE_DEVICE=1: both ranks use device 0, exchanges over gloo instead of RCCL): rank 0 prints ONE
-    JSON line whose value aggregates the chains of both ranks."""
-    d = _run_bench_ranks(tmp_path, 2, ["--steps", "40", "--warmup", "8", "--chains-per-gpu", "2", "--config", "cfg2", "--no-cpu-baseline"],
-                         dict(BNR_BENCH_ONE_DEVICE="1"))
-    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["warmup"] == 8 and d["scaling"] == "weak" and d["higher_is_better"] is True
-    assert "4 chains total" in d["config"]["workload"] and d["value"] > 0 and d["roofline"]["achieved"] > 0
-    assert abs(d["value"] - 4 * 40 / (d["ms_per_step"] * 40 / 1e3)) < 1e-6 * d["value"]
-    assert d["counters"]["chol_fail"] == 0 and d["single_chain"]["value"] > 0
+    this one GPU (BNR_BENCH_ONE_DEVICE=1: both ranks use device 0, exchanges over gloo instead of RCCL): BASELINE configs[2]'s
+    layout -- 8 chains IN ALL, chain c on rank (c-1) % 2, i.e. 4 per rank as one lockstep group -- rank 0 prints ONE JSON line whose
+    value aggregates the chains of both ranks ("strong": the total work does not grow with N); the 8-chains-on-every-GPU figure is
+    the weak_scaling sub-record."""
+    d = _run_bench_ranks(tmp_path, 2, ["--steps", "40", "--warmup", "8", "--config", "cfg2", "--no-cpu-baseline"], dict(BNR_BENCH_ONE_DEVICE="1"))
+    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["warmup"] == 8 and d["scaling"] == "strong" and d["higher_is_better"] is True
+    assert "8 chains total, 4 per GPU" in d["config"]["workload"] and d["config"]["chains_total"] == 8 and d["config"]["chains_per_gpu"] == 4
+    assert d["value"] > 0 and d["roofline"]["achieved"] > 0
+    assert abs(d["value"] - 8 * 40 / (d["ms_per_step"] * 40 / 1e3)) < 1e-6 * d["value"]
+    assert d["counters"]["chol_fail"] == 0 and "single_chain" not in d
+    w = d["weak_scaling"]
+    assert w["scaling"] == "weak" and w["chains_per_gpu"] == 8 and w["chains_total"] == 16 and w["value"] > 0
     assert d["rhat_exchange"].startswith("bnr_rhat: host-callback"), d["rhat_exchange"]
     assert d["timed_region"]["sweeps_launched_eagerly"] == 0 and d["timed_region"]["sweeps_replayed_from_graphs"] == 40
 
 
 def test_bench_one_rank_rccl_path(gpu, tmp_path):
-    """The torch.distributed path of bench.py on hardware with the backend the driver's N > 1 runs use (nccl = RCCL): one rank
-    under torch.distributed.run -- communicator creation, barrier, max-all-reduce of the timing and the all-gather of the
-    per-chain Rhat messages as device tensors (everything of the N > 1 path except the peers)."""
-    d = _run_bench_ranks(tmp_path, 1, ["--steps", "24", "--warmup", "3", "--chains-per-gpu", "2", "--config", "cfg2", "--no-cpu-baseline"],
+    """The N > 1 path of bench.py on hardware with ONE rank under torch.distributed.run: rendezvous over gloo, the library's own RCCL
+    communicator (ncclCommInitRank of world size 1), the timing's max over ranks and bnr_rhat's exchange -- k_rhat_stats writes the
+    per-chain messages into the communicator's device buffer, ncclAllGather (also with one rank the collective itself is called:
+    the dlsym'd signature, the datatype code, the staging buffers and the stream are the ones eight ranks use), one copy to the
+    host.  Everything of the N > 1 path except the peers."""
+    d = _run_bench_ranks(tmp_path, 1, ["--steps", "24", "--warmup", "3", "--chains", "2", "--config", "cfg2", "--no-cpu-baseline"],
                          dict(BNR_BENCH_FORCE_DIST="1"))
-    assert d["n_gpus"] == 1 and d["steps"] == 24 and d["value"] > 0 and d["max_rhat_gamma"] > 0
+    assert d["n_gpus"] == 1 and d["steps"] == 24 and d["value"] > 0 and d["max_rhat_gamma"] > 0 and d["config"]["chains_total"] == 2
     assert d["rhat_exchange"].startswith("bnr_rhat: ncclAllGather"), d["rhat_exchange"]
     assert d["timed_region"]["sweeps_launched_eagerly"] == 0 and d["timed_region"]["sweeps_replayed_from_graphs"] == 24
     assert 0 < d["roofline"]["sweep_frac"] < 1 and 0 < d["roofline"]["frac"] < 1
@@ -80,8 +86,10 @@ def test_bench_one_rank_rccl_path(gpu, tmp_path):
 _RANK_WORKER = r"""
 import os, sys
 sys.path.insert(0, {root!r})
-import numpy as np, torch.distributed as dist
+import numpy as np
 import bnr_amd
+bnr_amd.lib(); bnr_amd.device_count()        # the library's HIP runtime comes up BEFORE torch maps its own copy (load-order guard of _capi.lib)
+import torch.distributed as dist
 rank = int(sys.argv[1]); os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
 dist.init_process_group("gloo", rank=rank, world_size=2)
