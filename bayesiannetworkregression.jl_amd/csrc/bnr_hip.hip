@@ -89,6 +89,7 @@ struct bnr_chain {
     int *pbase_dev = nullptr;
     size_t trace_bytes = 0;
     struct bnr_group *group = nullptr;   // lockstep group this chain belongs to (at most one)
+    const unsigned char *x8_kept = nullptr;   // the byte image of X while option "byte_x" is 0
 };
 
 struct bnr_group {
@@ -200,7 +201,7 @@ struct x_source {
 };
 static size_t dtype_size(int t) { return t == BNR_U8 ? 1 : (t == BNR_I32 || t == BNR_F32) ? 4 : 8; }
 // raw (host layout, any element type) -> the padded f64 device matrix; the conversion runs on the device
-static int upload_x(bnr_chain *c, const x_source &src, double *Xd)
+static int upload_x(bnr_chain *c, const x_source &src, double *Xd, unsigned char *X8, int *not_bytes_dev)
 {
     const bnr_dev &d = c->d;
     const size_t es = dtype_size(src.dtype);
@@ -221,11 +222,11 @@ static int upload_x(bnr_chain *c, const x_source &src, double *Xd)
     if (e == hipSuccess) {
         const dim3 grid((d.n + 63) / 64, std::min(d.q, 65535)), block(64);
         switch (src.dtype) {
-        case BNR_U8:  hipLaunchKernelGGL(k_x_convert<uint8_t>, grid, block, 0, c->x.stream, (const uint8_t *)raw, src.mats != nullptr, d.n, d.V, d.q, d.n_pad, d.ek, d.el, Xd); break;
-        case BNR_I32: hipLaunchKernelGGL(k_x_convert<int32_t>, grid, block, 0, c->x.stream, (const int32_t *)raw, src.mats != nullptr, d.n, d.V, d.q, d.n_pad, d.ek, d.el, Xd); break;
-        case BNR_I64: hipLaunchKernelGGL(k_x_convert<int64_t>, grid, block, 0, c->x.stream, (const int64_t *)raw, src.mats != nullptr, d.n, d.V, d.q, d.n_pad, d.ek, d.el, Xd); break;
-        case BNR_F32: hipLaunchKernelGGL(k_x_convert<float>, grid, block, 0, c->x.stream, (const float *)raw, src.mats != nullptr, d.n, d.V, d.q, d.n_pad, d.ek, d.el, Xd); break;
-        default:      hipLaunchKernelGGL(k_x_convert<double>, grid, block, 0, c->x.stream, (const double *)raw, src.mats != nullptr, d.n, d.V, d.q, d.n_pad, d.ek, d.el, Xd); break;
+        case BNR_U8:  hipLaunchKernelGGL(k_x_convert<uint8_t>, grid, block, 0, c->x.stream, (const uint8_t *)raw, src.mats != nullptr, d.n, d.V, d.q, d.n_pad, d.ek, d.el, Xd, X8, not_bytes_dev); break;
+        case BNR_I32: hipLaunchKernelGGL(k_x_convert<int32_t>, grid, block, 0, c->x.stream, (const int32_t *)raw, src.mats != nullptr, d.n, d.V, d.q, d.n_pad, d.ek, d.el, Xd, X8, not_bytes_dev); break;
+        case BNR_I64: hipLaunchKernelGGL(k_x_convert<int64_t>, grid, block, 0, c->x.stream, (const int64_t *)raw, src.mats != nullptr, d.n, d.V, d.q, d.n_pad, d.ek, d.el, Xd, X8, not_bytes_dev); break;
+        case BNR_F32: hipLaunchKernelGGL(k_x_convert<float>, grid, block, 0, c->x.stream, (const float *)raw, src.mats != nullptr, d.n, d.V, d.q, d.n_pad, d.ek, d.el, Xd, (unsigned char *)nullptr, not_bytes_dev); break;
+        default:      hipLaunchKernelGGL(k_x_convert<double>, grid, block, 0, c->x.stream, (const double *)raw, src.mats != nullptr, d.n, d.V, d.q, d.n_pad, d.ek, d.el, Xd, (unsigned char *)nullptr, not_bytes_dev); break;
         }
         e = hipStreamSynchronize(c->x.stream);
     }
@@ -320,7 +321,7 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     TRY(exec_init(c->x, device, 1, &c->d));
     if (donor) {
         c->in = donor->in;
-        d.X = donor->d.X; d.y = donor->d.y; d.ek = donor->d.ek; d.el = donor->d.el; d.gmap = donor->d.gmap; d.gmapc = donor->d.gmapc;
+        d.X = donor->d.X; d.X8 = donor->d.X8; d.y = donor->d.y; d.ek = donor->d.ek; d.el = donor->d.el; d.gmap = donor->d.gmap; d.gmapc = donor->d.gmapc;
     } else {
         c->in = std::make_shared<bnr_inputs>();
         double *Xd = nullptr, *yd = nullptr;
@@ -344,7 +345,21 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
             HIPNOTE(hipMemcpy(el, hl.data(), d.q * sizeof(int), hipMemcpyHostToDevice));
         }
         d.ek = ek; d.el = el;
-        TRY(upload_x(c, xs, Xd));
+        // 0..255-valued integer input (Bool / UInt8 always, Int32 / Int64 if every value fits): a byte image of X for the X passes
+        unsigned char *X8 = nullptr;
+        int *nb = nullptr;
+        if (xs.dtype == BNR_U8 || xs.dtype == BNR_I32 || xs.dtype == BNR_I64) {
+            TRY(in_alloc((void **)&X8, (size_t)d.n_pad * (d.q_pad + 64)));
+            TRY(in_alloc((void **)&nb, sizeof(int)));
+        }
+        TRY(upload_x(c, xs, Xd, X8, nb));
+        if (X8) {
+            int not_bytes = 0;
+            if (hipMemcpy(&not_bytes, nb, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "copy failed"); }
+            const char *off = getenv("BNR_NO_BYTE_X");
+            if (not_bytes || (off && atoi(off))) X8 = nullptr;         // (the buffer stays with the inputs and is freed with them)
+        }
+        d.X8 = X8;
         {
             // XCD-aware task map of k_gram (tasks = lower tiles x K slices): workgroup i runs on XCD i % 8; give it a K
             // slice ks with ks % 8 == i % 8 while there are any, so that a slice of X is read through one XCD's L2
@@ -1095,7 +1110,8 @@ static int exec_last_timing(bnr_exec &x, int which, double *avg_us, int64_t *lau
     if (which == 0) { *avg_us = x.t_iter_us; if (launches) *launches = x.n_iter; }
     else if (which == 1) { *avg_us = x.t_gram_us; if (launches) *launches = x.n_gram; }
     else if (which == 2) { *avg_us = (double)x.n_eager; if (launches) *launches = x.n_replayed; }   // how the last run call was issued
-    else return fail(BNR_ERR_BAD_ARG, "which must be 0, 1 or 2");
+    else if (which == 3) { *avg_us = x.shape->X8 ? 1.0 : 0.0; if (launches) *launches = x.shape->X8 ? 1 : 0; }   // do the X passes read a byte image of X
+    else return fail(BNR_ERR_BAD_ARG, "which must be 0, 1, 2 or 3");
     return BNR_OK;
 }
 // Replay both captured graphs ONCE on scratch rows, results discarded: the first replay of an instantiated graph pays for the
@@ -1897,6 +1913,15 @@ int bnr_chain_last_timing(bnr_chain *c, int32_t which, double *avg_us, int64_t *
 int bnr_chain_set_option(bnr_chain *c, const char *name, int64_t value)
 {
     if (!c || !name) return fail(BNR_ERR_BAD_ARG, "NULL argument");
+    if (!strcmp(name, "byte_x")) {
+        // 0: the X passes read the f64 matrix also when a byte image exists; 1: back to the byte image (if the input had one)
+        if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");
+        if (!c->x8_kept) c->x8_kept = c->d.X8;
+        c->d.X8 = value ? c->x8_kept : nullptr;
+        drop_graph(c->x);
+        if (c->group) drop_graph(c->group->x);
+        return sync_dev(c);
+    }
     return exec_set_option(c->x, name, value);
 }
 

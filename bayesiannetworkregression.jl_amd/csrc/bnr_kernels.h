@@ -39,6 +39,8 @@ struct bnr_dev {
     uint64_t seed;
     // inputs
     const double *X, *y;
+    const unsigned char *X8;     // X once more as BYTES (same padded layout) when the caller's model matrix is 0..255-valued (Bool adjacency
+                                 // data, gibbs.jl:907-918): the two bandwidth-bound passes over X read an eighth of the bytes; nullptr otherwise
     const int *ek, *el;          // edge e -> column node k, row node l (l >= k)
     // state
     double *trace;
@@ -80,7 +82,7 @@ struct bnr_dev {
 __device__ __forceinline__ bnr_dev bnr_globalized(const bnr_dev *src)
 {
     bnr_dev d = *src;
-    BNR_GLOBAL_PTR(X); BNR_GLOBAL_PTR(y); BNR_GLOBAL_PTR(ek); BNR_GLOBAL_PTR(el); BNR_GLOBAL_PTR(trace); BNR_GLOBAL_PTR(plan);
+    BNR_GLOBAL_PTR(X); BNR_GLOBAL_PTR(X8); BNR_GLOBAL_PTR(y); BNR_GLOBAL_PTR(ek); BNR_GLOBAL_PTR(el); BNR_GLOBAL_PTR(trace); BNR_GLOBAL_PTR(plan);
     BNR_GLOBAL_PTR(pbase); BNR_GLOBAL_PTR(Wbuf); BNR_GLOBAL_PTR(sz); BNR_GLOBAL_PTR(PW); BNR_GLOBAL_PTR(PA); BNR_GLOBAL_PTR(PG);
     BNR_GLOBAL_PTR(Gpart); BNR_GLOBAL_PTR(E); BNR_GLOBAL_PTR(gmap); BNR_GLOBAL_PTR(a3); BNR_GLOBAL_PTR(xw); BNR_GLOBAL_PTR(a4);
     BNR_GLOBAL_PTR(res); BNR_GLOBAL_PTR(xg); BNR_GLOBAL_PTR(bw); BNR_GLOBAL_PTR(wv); BNR_GLOBAL_PTR(scal); BNR_GLOBAL_PTR(Minv);
@@ -410,17 +412,19 @@ __global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int w
     __syncthreads();
     const size_t ld = cd.n_pad;
     for (int i = threadIdx.x; i < cd.n_pad; i += blockDim.x) {
-        const double *xp = cd.X + (size_t)e0 * ld + i;
         double aw = 0.0, aa = 0.0, ag = 0.0;
-        if ((which & 7) == 3) {
-#pragma unroll 4
-            for (int t = 0; t < ne; ++t) { double x = xp[(size_t)t * ld]; aw = fma(x, sW[t], aw); aa = fma(x, sZ[t], aa); }
-        } else {
-            for (int t = 0; t < ne; ++t) {
-                double x = xp[(size_t)t * ld];
-                aw = fma(x, sW[t], aw); aa = fma(x, sZ[t], aa); ag = fma(x, sG[t], ag);
-            }
+        // the same fused multiply-adds in the same order from either image of X (a byte converts exactly)
+#define BNR_XPASS_BODY(XP)                                                                                          \
+        if ((which & 7) == 3) {                                                                                     \
+            _Pragma("unroll 4") for (int t = 0; t < ne; ++t) { double x = (double)(XP)[(size_t)t * ld]; aw = fma(x, sW[t], aw); aa = fma(x, sZ[t], aa); } \
+        } else {                                                                                                    \
+            for (int t = 0; t < ne; ++t) {                                                                          \
+                double x = (double)(XP)[(size_t)t * ld];                                                            \
+                aw = fma(x, sW[t], aw); aa = fma(x, sZ[t], aa); ag = fma(x, sG[t], ag);                             \
+            }                                                                                                       \
         }
+        if (cd.X8) { const unsigned char *xp = cd.X8 + (size_t)e0 * ld + i; BNR_XPASS_BODY(xp) }
+        else { const double *xp = cd.X + (size_t)e0 * ld + i; BNR_XPASS_BODY(xp) }
         if (which & 1) cd.PW[(size_t)bid * ld + i] = aw;
         if (which & 2) cd.PA[(size_t)bid * ld + i] = aa;
         if (which & 4) cd.PG[(size_t)bid * ld + i] = ag;
@@ -1687,11 +1691,17 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
         __syncthreads();
         for (int t = wave; t < ne; t += 8) {
             const int t2 = t + 4;
-            const double *xc = cd.X + (size_t)(e0 + t) * ld;
-            const double *xd = cd.X + (size_t)(e0 + (t2 < ne ? t2 : t)) * ld;
+            const size_t oc = (size_t)(e0 + t) * ld, od = (size_t)(e0 + (t2 < ne ? t2 : t)) * ld;
             double acc0 = 0.0, acc1 = 0.0;
+            if (cd.X8) {
+                const unsigned char *xc = cd.X8 + oc, *xd = cd.X8 + od;
 #pragma unroll 4
-            for (int i = lane; i < cd.n_pad; i += 64) { double av = sa[i]; acc0 = fma(xc[i], av, acc0); acc1 = fma(xd[i], av, acc1); }
+                for (int i = lane; i < cd.n_pad; i += 64) { double av = sa[i]; acc0 = fma((double)xc[i], av, acc0); acc1 = fma((double)xd[i], av, acc1); }
+            } else {
+                const double *xc = cd.X + oc, *xd = cd.X + od;
+#pragma unroll 4
+                for (int i = lane; i < cd.n_pad; i += 64) { double av = sa[i]; acc0 = fma(xc[i], av, acc0); acc1 = fma(xd[i], av, acc1); }
+            }
             acc0 = wave_sum(acc0); acc1 = wave_sum(acc1);
             if (lane == 0) { sdot[t] = acc0; if (t2 < ne) sdot[t2] = acc1; }
         }
@@ -2156,14 +2166,21 @@ __global__ __launch_bounds__(256) void k_init_prior(bnr_dev cd)
 // matrices themselves (V x V column-major, one after the other): setup_X! on the device (gibbs.jl:239-247), row i =
 // lower_triangle(A_i), i.e. edge e <-> (l >= k) reads A_i[l, k] (utils.jl:50-55).  grid = (ceil(n/64), edges), 64 threads.
 template <typename T>
-__global__ void k_x_convert(const T *raw, bool from_matrices, int n, int V, int q, int n_pad, const int *ek, const int *el, double *X)
+__global__ void k_x_convert(const T *raw, bool from_matrices, int n, int V, int q, int n_pad, const int *ek, const int *el, double *X, unsigned char *X8, int *not_bytes)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
+    bool bad = false;
     for (int e = blockIdx.y; e < q; e += gridDim.y) {
         const T v = from_matrices ? raw[(size_t)i * V * V + (size_t)el[e] + (size_t)V * ek[e]] : raw[(size_t)i + (size_t)n * e];
         X[(size_t)i + (size_t)n_pad * e] = (double)v;
+        if (X8) {
+            const unsigned char b = (unsigned char)v;
+            if ((T)b != v) bad = true;                            // not a whole number in 0..255: the byte image is dropped by the host
+            X8[(size_t)i + (size_t)n_pad * e] = b;
+        }
     }
+    if (bad) *not_bytes = 1;
 }
 
 // ===================================================================================== table transposes

@@ -228,7 +228,13 @@ int bnr_chain_debug_copy(bnr_chain *chain, int32_t which, double *out, int64_t c
  *   "overlap"   1 (default): scalar branch and Gram/factorization branch of a sweep on two streams; 0: one stream
  *   "gram_variant" 0 (default): the Gram kernel is chosen per launch (k_gram8 when the launch has more than two workgroups per CU,
  *               k_gram otherwise); 8 / 16 force one of them.  Both write the same partial tiles bit for bit.
- *   "profiling" 1: record HIP events around every k_gram launch (forces eager launches), see bnr_chain_last_timing */
+ *   "profiling" 1: record HIP events around every k_gram launch (forces eager launches), see bnr_chain_last_timing
+ *   "factor_variant" 0 / -1 (default): right-looking factorization (k_gram_reduce + k_chol_step); 1: left-looking (k_chol_ll)
+ *   "pipeline"  1 (needs factor_variant 1): factorization beside the Gram (persistent Gram off the reserved CUs, gates per tile column)
+ *   "gate_us"   how long a gate of the pipelined schedule polls before it gives up (default 3000)
+ *   "byte_x"    (chains only) 0: the X passes read the f64 matrix although a byte image of X exists; 1 (default): the byte image
+ *               (kept when the model matrix came as Bool/UInt8, or as Int32/Int64 with every value in 0..255; docs/src/man/inputdata.md)
+ * All variants give the same tables bit for bit.  bnr_chain_last_timing(which = 3) says whether a byte image is in use. */
 int bnr_chain_set_option(bnr_chain *chain, const char *name, int64_t value);
 
 /* Host-side copies of the draw-site primitives (same source as the device functions), exported so that the

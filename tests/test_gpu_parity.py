@@ -582,8 +582,10 @@ def test_input_formats_are_converted_on_the_device(gpu):
     mats_int = [np.tril(rng.integers(0, 6, (V, V))) + np.triu(rng.integers(0, 6, (V, V)), 1) for _ in range(n)]   # not symmetric
     y = rng.normal(size=n)
 
-    def table(X, x_transform):
+    def table(X, x_transform, bytes_expected=None):
         ch = bnr_amd.Chain(bnr_amd.XInput(X, x_transform), y, R, tot, 11, 1)
+        if bytes_expected is not None:                                                  # 0..255-valued integer input keeps a byte image of X
+            assert (ch.last_timing(3)[1] == 1) == bytes_expected, (np.asarray(X[0]).dtype, x_transform)
         ch.init_prior()
         ch.run(2, tot, tot)
         t = ch.fetch()
@@ -599,9 +601,17 @@ def test_input_formats_are_converted_on_the_device(gpu):
                     "matrix uint8": (Xh.astype(np.uint8), False), "matrix f32": (Xh.astype(np.float32), False),
                     "matrix int16 (promoted on the host)": (Xh.astype(np.int16), False)}
         for name, (X, tr) in variants.items():
-            got = table(X, tr)
+            narrow = np.asarray(X[0]).dtype in (np.dtype(bool), np.dtype(np.uint8), np.dtype(np.int32), np.dtype(np.int64))
+            got = table(X, tr, bytes_expected=narrow)
             for k in bo.COLUMNS:
                 assert np.array_equal(got[k], want[k]), (name, k)
+    # an integer matrix with an entry outside 0..255 keeps no byte image (and still gives the f64 table)
+    Xbig = bnr_amd.setup_X(mats_int, True)[0].astype(np.int64)
+    Xbig[3, 4] = 256
+    wantb = table(Xbig.astype(np.float64), False, bytes_expected=False)
+    gotb = table(Xbig, False, bytes_expected=False)
+    for k in bo.COLUMNS:
+        assert np.array_equal(gotb[k], wantb[k]), ("int64 with 256", k)
     o = bo.Oracle(bnr_amd.setup_X(mats_int, True)[0], y, R, tot, 11, chain=1, pdf_mode=1)
     o.init_prior()
     o.run(2, tot, tot)
@@ -611,6 +621,49 @@ def test_input_formats_are_converted_on_the_device(gpu):
     assert res.state["gamma"].shape == (10, V * (V + 1) // 2, 1)
     with pytest.raises(ValueError):
         bnr_amd.XInput([np.zeros((3, 3)), np.zeros((4, 4))], True)
+
+
+def test_byte_image_of_a_binary_model_matrix_at_config5_size(gpu):
+    """SURVEY 8f-2 (gibbs.jl:239-247, 907-918; docs/src/man/inputdata.md:5-10: adjacency data is Bool): at BASELINE configs[4]'s size
+    (n=500, V=300, q=45 150: X = 180.6 MB as Float64, 22.6 MB as bytes) a 0/1 model matrix stays in HBM as bytes for the two bandwidth-bound
+    passes over X (k_xpass, k_backproj); the tables are bitwise those of the same chain reading the f64 image (option byte_x = 0), of the
+    same data given as float64, alone and as members of a lockstep group."""
+    n, V, R, tot = 500, 300, 10, 4
+    rng = np.random.default_rng(9)
+    q = V * (V + 1) // 2
+    Xb = rng.random((n, q)) < 0.5
+    y = rng.normal(size=n)
+    want = None
+    for name, X, byte_x in (("float64", Xb.astype(np.float64), None), ("bool, bytes", Xb, 1), ("bool, f64 image", Xb, 0)):
+        ch = bnr_amd.Chain(bnr_amd.XInput(np.asfortranarray(X), False), y, R, tot, 21, 1)
+        mate = bnr_amd.Chain.like(ch, 21, 2, tot)
+        if byte_x is not None:
+            assert ch.last_timing(3)[1] == 1
+            for c in (ch, mate):
+                c.set_option("byte_x", byte_x)
+            assert ch.last_timing(3)[1] == byte_x
+        else:
+            assert ch.last_timing(3)[1] == 0
+        for c in (ch, mate):
+            c.init_prior()
+        g = bnr_amd.Group([ch, mate])
+        g.run(2, tot, tot)
+        solo = bnr_amd.Chain.like(ch, 21, 1, tot)
+        if byte_x is not None:
+            solo.set_option("byte_x", byte_x)
+        solo.init_prior()
+        solo.run(2, tot, tot)
+        tabs = (ch.fetch(), solo.fetch())
+        assert ch.counters()["chol_fail"] == 0
+        g.close()
+        for c in (ch, mate, solo):
+            c.close()
+        for k in bo.COLUMNS:
+            assert np.isfinite(tabs[0][k]).all()
+            assert np.array_equal(tabs[0][k], tabs[1][k]), (name, "group vs alone", k)
+            if want is not None:
+                assert np.array_equal(tabs[0][k], want[k]), (name, k)
+        want = want or tabs[0]
 
 
 def test_device_summary_equals_host_summary(gpu, test1):
