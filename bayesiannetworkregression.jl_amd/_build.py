@@ -3,10 +3,12 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "libbnr_hip.so")
+LIB = os.environ.get("BNR_HIP_LIB") or os.path.join(HERE, "libbnr_hip.so")     # BNR_HIP_LIB: another build of the library (the sanitizer build of tools/sanitize_cpu.sh; julia/BNRHip.jl honours the same variable)
 
 
 def build(force=False, verbose=False):
+    if os.environ.get("BNR_HIP_LIB"):
+        return LIB
     csrc = os.path.join(HERE, "csrc")
     cmd = ["make", "-C", csrc] + (["-B"] if force else [])
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -70,7 +70,7 @@ struct bnr_exec {
 // with bnr_chain_create_like, freed with the last of them
 struct bnr_inputs {
     std::vector<void *> bufs;
-    ~bnr_inputs() { for (void *p : bufs) hipFree(p); }
+    ~bnr_inputs() { for (void *p : bufs) (void)hipFree(p); }
 };
 
 struct bnr_chain {
@@ -215,7 +215,7 @@ static int upload_x(bnr_chain *c, const x_source &src, double *Xd, unsigned char
     hipError_t e = hipSuccess;
     if (src.mats) {
         for (int i = 0; i < d.n && e == hipSuccess; ++i) {
-            if (!src.mats[i]) { hipFree(raw); return fail(BNR_ERR_BAD_ARG, "NULL adjacency matrix"); }
+            if (!src.mats[i]) { (void)hipFree(raw); return fail(BNR_ERR_BAD_ARG, "NULL adjacency matrix"); }
             e = hipMemcpyAsync((char *)raw + (size_t)i * d.V * d.V * es, src.mats[i], (size_t)d.V * d.V * es, hipMemcpyHostToDevice, c->x.stream);
         }
     } else e = hipMemcpyAsync(raw, src.X, count * es, hipMemcpyHostToDevice, c->x.stream);
@@ -486,7 +486,7 @@ static const unsigned *reserved_cus(int device, int per_se)
         }
         ok = hipMemcpy(d, h, 32 * sizeof(unsigned), hipMemcpyHostToDevice) == hipSuccess;
     }
-    if (!ok) { hipFree(d); return nullptr; }
+    if (!ok) { (void)hipFree(d); return nullptr; }
     tab[device] = d;
     return d;
 }
@@ -522,16 +522,16 @@ static void exec_free(bnr_exec &x)
     if (x.stream2) { (void)hipStreamSynchronize(x.stream2); }
     if (x.stream3) { (void)hipStreamSynchronize(x.stream3); (void)hipStreamDestroy(x.stream3); }
     if (x.stream4) { (void)hipStreamSynchronize(x.stream4); (void)hipStreamDestroy(x.stream4); }
-    if (x.gctl) hipFree(x.gctl);
+    if (x.gctl) (void)hipFree(x.gctl);
     drop_graph(x);
     if (x.stream) (void)hipStreamDestroy(x.stream);
     if (x.stream2) (void)hipStreamDestroy(x.stream2);
-    for (hipEvent_t e : x.fj) hipEventDestroy(e);
-    for (hipEvent_t e : x.ev) hipEventDestroy(e);
-    if (x.cds) hipFree(x.cds);
-    if (x.cds_pin) hipHostFree(x.cds_pin);
-    if (x.status_dev) hipFree(x.status_dev);
-    if (x.status_pin) hipHostFree(x.status_pin);
+    for (hipEvent_t e : x.fj) (void)hipEventDestroy(e);
+    for (hipEvent_t e : x.ev) (void)hipEventDestroy(e);
+    if (x.cds) (void)hipFree(x.cds);
+    if (x.cds_pin) (void)hipHostFree(x.cds_pin);
+    if (x.status_dev) (void)hipFree(x.status_dev);
+    if (x.status_pin) (void)hipHostFree(x.status_pin);
     x = bnr_exec();
 }
 // the kernels read the chain's bnr_dev from device memory: refresh the copy whenever the host struct changes
@@ -557,10 +557,10 @@ int bnr_chain_destroy(bnr_chain *c)
         g->m.clear();
     }
     exec_free(c->x);
-    for (void *p : c->allocs) hipFree(p);
-    if (c->d.trace) hipFree(c->d.trace);
-    if (c->plan_pin) hipHostFree(c->plan_pin);
-    if (c->counters_host) hipHostFree(c->counters_host);
+    for (void *p : c->allocs) (void)hipFree(p);
+    if (c->d.trace) (void)hipFree(c->d.trace);
+    if (c->plan_pin) (void)hipHostFree(c->plan_pin);
+    if (c->counters_host) (void)hipHostFree(c->counters_host);
     delete c;
     return BNR_OK;
 }
@@ -953,7 +953,7 @@ static int run_exec(bnr_exec &x, int first_index, int count, int prog_freq, bnr_
     hipLaunchKernelGGL(k_setbase, dim3(x.nb), dim3(1), 0, x.stream, (const bnr_dev *)x.cds, 1);
     x.t_gram_acc = 0; x.n_gram = 0; x.n_replayed = 0; x.n_eager = 0;
     hipEvent_t r0 = nullptr, r1 = nullptr;
-    if (x.profiling) { HIPCHK(hipEventCreate(&r0)); HIPCHK(hipEventCreate(&r1)); hipEventRecord(r0, x.stream); }
+    if (x.profiling) { HIPCHK(hipEventCreate(&r0)); HIPCHK(hipEventCreate(&r1)); HIPNOTE(hipEventRecord(r0, x.stream)); }
     if (cb && prog_freq > 0) {
         int s = 0;
         while (s < count) {
@@ -985,7 +985,7 @@ static int run_exec(bnr_exec &x, int first_index, int count, int prog_freq, bnr_
         HIPNOTE(hipEventElapsedTime(&ms, r0, r1));
         x.t_iter_us = 1e3 * ms / count; x.n_iter = count;
         x.t_gram_us = x.n_gram ? 1e3 * x.t_gram_acc / x.n_gram : 0;
-        (void)hipEventDestroy(r0); hipEventDestroy(r1);
+        (void)hipEventDestroy(r0); (void)hipEventDestroy(r1);
     }
     return BNR_OK;
 }
@@ -1515,8 +1515,8 @@ static int comm_reserve(bnr_comm *c, size_t count)
 {
     if (count <= c->dcap) return BNR_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->dsend) hipFree(c->dsend);
-    if (c->drecv) hipFree(c->drecv);
+    if (c->dsend) (void)hipFree(c->dsend);
+    if (c->drecv) (void)hipFree(c->drecv);
     c->dsend = c->drecv = nullptr; c->dcap = 0;
     const size_t cap = std::max<size_t>(count, 1024);
     HIPCHK(hipMalloc((void **)&c->dsend, sizeof(double) * cap));
@@ -1611,8 +1611,8 @@ int bnr_comm_destroy(bnr_comm *c)
 {
     if (!c) return BNR_OK;
     if (c->nccl) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); g_rccl.CommDestroy(c->nccl); }
-    if (c->dsend) hipFree(c->dsend);
-    if (c->drecv) hipFree(c->drecv);
+    if (c->dsend) (void)hipFree(c->dsend);
+    if (c->drecv) (void)hipFree(c->drecv);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return BNR_OK;
@@ -1717,7 +1717,7 @@ int bnr_chain_summary(bnr_chain *c, int32_t first_row, int32_t nsamp, int32_t k_
     const int np = d.q + d.V;
     double *buf = nullptr, *out = nullptr;
     HIPCHK(hipMalloc((void **)&buf, sizeof(double) * (size_t)np * nsamp));
-    if (hipMalloc((void **)&out, sizeof(double) * 3 * (size_t)np) != hipSuccess) { hipFree(buf); return fail(BNR_ERR_HIP, "hipMalloc failed"); }
+    if (hipMalloc((void **)&out, sizeof(double) * 3 * (size_t)np) != hipSuccess) { (void)hipFree(buf); return fail(BNR_ERR_HIP, "hipMalloc failed"); }
     dim3 block(32, 8);
     hipLaunchKernelGGL(k_fetch_cols, dim3((d.q + 31) / 32, (nsamp + 31) / 32), block, 0, c->x.stream, (const double *)d.trace, d.rowlen, d.o_gamma, d.q, first_row - 1, nsamp, buf);
     hipLaunchKernelGGL(k_fetch_cols, dim3((d.V + 31) / 32, (nsamp + 31) / 32), block, 0, c->x.stream, (const double *)d.trace, d.rowlen, d.o_xi, d.V, first_row - 1, nsamp, buf + (size_t)d.q * nsamp);
@@ -1725,7 +1725,7 @@ int bnr_chain_summary(bnr_chain *c, int32_t first_row, int32_t nsamp, int32_t k_
     std::vector<double> host(3 * (size_t)np);
     hipError_t e = hipMemcpyAsync(host.data(), out, sizeof(double) * host.size(), hipMemcpyDeviceToHost, c->x.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->x.stream);
-    (void)hipFree(buf); hipFree(out);
+    (void)hipFree(buf); (void)hipFree(out);
     if (e != hipSuccess) return fail(BNR_ERR_HIP, std::string("summary: ") + hipGetErrorString(e));
     memcpy(mean_gamma, host.data(), sizeof(double) * d.q);
     memcpy(prob_xi, host.data() + d.q, sizeof(double) * d.V);
@@ -1748,14 +1748,14 @@ int bnr_chain_ess_stats(bnr_chain *c, int32_t first_row, int32_t nsamp, int32_t 
     const size_t width = (size_t)2 * (2 + max_lag) * np;
     double *buf = nullptr, *out = nullptr;
     HIPCHK(hipMalloc((void **)&buf, sizeof(double) * (size_t)np * nsamp));
-    if (hipMalloc((void **)&out, sizeof(double) * width) != hipSuccess) { hipFree(buf); return fail(BNR_ERR_HIP, "hipMalloc failed"); }
+    if (hipMalloc((void **)&out, sizeof(double) * width) != hipSuccess) { (void)hipFree(buf); return fail(BNR_ERR_HIP, "hipMalloc failed"); }
     dim3 block(32, 8);
     hipLaunchKernelGGL(k_fetch_cols, dim3((d.q + 31) / 32, (nsamp + 31) / 32), block, 0, c->x.stream, (const double *)d.trace, d.rowlen, d.o_gamma, d.q, first_row - 1, nsamp, buf);
     hipLaunchKernelGGL(k_fetch_cols, dim3((d.V + 31) / 32, (nsamp + 31) / 32), block, 0, c->x.stream, (const double *)d.trace, d.rowlen, d.o_xi, d.V, first_row - 1, nsamp, buf + (size_t)d.q * nsamp);
     hipLaunchKernelGGL(k_acov, dim3(np, 2), dim3(256), 0, c->x.stream, (const double *)buf, nsamp, np, max_lag, out);
     hipError_t e = hipMemcpyAsync(stats, out, sizeof(double) * width, hipMemcpyDeviceToHost, c->x.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->x.stream);
-    (void)hipFree(buf); hipFree(out);
+    (void)hipFree(buf); (void)hipFree(out);
     if (e != hipSuccess) return fail(BNR_ERR_HIP, std::string("ess_stats: ") + hipGetErrorString(e));
     return check_launch("k_acov");
 }
@@ -1893,7 +1893,7 @@ int bnr_chain_debug_time_gram(bnr_chain *c, int32_t reps, double *avg_us)
     HIPCHK(hipStreamSynchronize(c->x.stream));
     float ms = 0;
     HIPNOTE(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_us = 1e3 * ms / reps;
     c->carried_row = -1;
     return check_launch("debug_time_gram");

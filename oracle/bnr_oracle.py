@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libbnr_oracle.so")
+_LIB = os.environ.get("BNR_ORACLE_LIB") or os.path.join(_HERE, "libbnr_oracle.so")     # BNR_ORACLE_LIB: the sanitizer build (tools/sanitize_cpu.sh)
 
 SITES = dict(INIT_S=1, INIT_PI=2, INIT_LAM=3, INIT_XI=4, INIT_M_CHI=5, INIT_M_N=6, INIT_U=7, INIT_GAMMA=8,
              TAU2=16, XI=17, U_Z=18, G_Z1=19, G_Z2=20, D_GIG=21, D_GAMMA=22, THETA=23, DELTA=24,
@@ -20,6 +20,8 @@ COLUMNS = ["tau2", "u", "xi", "gamma", "S", "theta", "Delta", "M", "mu", "lam", 
 
 def build(force=False):
     src = os.path.join(_HERE, "bnr_oracle.c")
+    if os.environ.get("BNR_ORACLE_LIB"):
+        return _LIB
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libbnr_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB
