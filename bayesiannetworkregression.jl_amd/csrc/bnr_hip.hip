@@ -47,6 +47,7 @@ struct bnr_exec {
     int pipeline = -1;                                  // -1: chosen by size / availability; 0: the factorization follows the Gram; 1: beside it
     int gate_us = 3000;                                 // how long a gate of the factorization polls for the Gram's progress
     unsigned *gctl = nullptr;                           // k_gram8p: queue heads and tickets
+    bnr_gramq gq{};                                     // k_gram8p: the per-XCD task lists inside gmapc (set by the owner from its inputs)
     const unsigned *resv = nullptr;                     // reserved compute units (device table shared per device), nullptr: none
     std::vector<hipEvent_t> fj;                         // fork/join events
     size_t fj_next = 0;
@@ -70,6 +71,7 @@ struct bnr_exec {
 // with bnr_chain_create_like, freed with the last of them
 struct bnr_inputs {
     std::vector<void *> bufs;
+    int gq_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};       // k_gram8p: queue x = gmapc[gq_off[x] .. gq_off[x + 1])
     ~bnr_inputs() { for (void *p : bufs) (void)hipFree(p); }
 };
 
@@ -326,6 +328,7 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
         c->in = std::make_shared<bnr_inputs>();
         double *Xd = nullptr, *yd = nullptr;
         int *ek = nullptr, *el = nullptr, *gm = nullptr, *gmc = nullptr;
+        int gq_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         auto in_alloc = [&](void **ptr, size_t bytes) -> int {
             HIPCHK(hipMalloc(ptr, std::max<size_t>(bytes, 8)));
             c->in->bufs.push_back(*ptr);
@@ -382,17 +385,35 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
             }
             TRY(in_alloc((void **)&gm, sizeof(int) * ntask));
             HIPNOTE(hipMemcpy(gm, map.data(), ntask * sizeof(int), hipMemcpyHostToDevice));
-            // k_gram8p: eight queues (K slices ks = x mod 8 on XCD x), each in tile-COLUMN order; offsets: gram_queues()
+            // k_gram8p: eight queues, one per XCD, each in tile-COLUMN order (the factorization consumes G column by column): the
+            // XCD-aware assignment of the static map above -- XCD x works through the K slices ks = x mod 8 and the XCDs without a
+            // slice of their own take an equal share from the END of the others' lists (cascading instead -- an XCD that has run dry
+            // helping its neighbour, which then runs dry early and moves on -- was measured: 3.5 x the L2 misses, 225 instead of 49 MB fetched)
             std::vector<int> mapc;
-            for (int x = 0; x < 8; ++x)
+            {
+                std::vector<std::vector<int>> qc(8), mine(8);
                 for (int tc = 0; tc < d.ntile; ++tc)
                     for (int ti = tc; ti < d.ntile; ++ti)
-                        for (int ks = x; ks < d.ksplit; ks += 8) mapc.push_back((ti * (ti + 1) / 2 + tc) | (ks << 16));
+                        for (int ks = 0; ks < d.ksplit; ++ks) qc[ks % 8].push_back((ti * (ti + 1) / 2 + tc) | (ks << 16));
+                const int share = (ntask + 7) / 8;
+                std::vector<int> spill;                                   // what exceeds an XCD's share, taken from the end of its list
+                for (int x = 0; x < 8; ++x) {
+                    while ((int)qc[x].size() > share) { spill.push_back(qc[x].back()); qc[x].pop_back(); }
+                    mine[x] = qc[x];
+                }
+                std::sort(spill.begin(), spill.end(), [](int a, int b) { return (a & 0xFFFF) != (b & 0xFFFF) ? (a & 0xFFFF) < (b & 0xFFFF) : a < b; });
+                for (int x = 0; x < 8 && !spill.empty(); ++x)
+                    while ((int)mine[x].size() < share && !spill.empty()) { mine[x].push_back(spill.front()); spill.erase(spill.begin()); }
+                for (int x = 0; x < 8; ++x) { gq_off[x] = (int)mapc.size(); mapc.insert(mapc.end(), mine[x].begin(), mine[x].end()); }
+                gq_off[8] = (int)mapc.size();
+            }
             TRY(in_alloc((void **)&gmc, sizeof(int) * ntask));
             HIPNOTE(hipMemcpy(gmc, mapc.data(), ntask * sizeof(int), hipMemcpyHostToDevice));
         }
         d.X = Xd; d.y = yd; d.ek = ek; d.el = el; d.gmap = gm; d.gmapc = gmc;
+        for (int x = 0; x < 9; ++x) c->in->gq_off[x] = gq_off[x];
     }
+    for (int x = 0; x < 9; ++x) c->x.gq.qoff[x] = c->in->gq_off[x];
     TRY(alloc_trace(c, tot_save, &d.trace));
     TRY(dev_alloc(c, &d.Wbuf, d.q_pad));
     TRY(dev_alloc(c, &d.sz, d.q_pad));
@@ -509,7 +530,6 @@ static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape)
     HIPCHK(hipStreamCreateWithFlags(&x.stream4, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void **)&x.gctl, 64));
     HIPCHK(hipMemset(x.gctl, 0, 64));
-    x.resv = reserved_cus(device, 1);
     HIPCHK(hipMalloc((void **)&x.cds, sizeof(bnr_dev) * nb));
     HIPCHK(hipHostMalloc((void **)&x.cds_pin, sizeof(bnr_dev) * nb));
     HIPCHK(hipMalloc((void **)&x.status_dev, sizeof(long long) * 16 * nb));
@@ -629,14 +649,7 @@ static bool pipelined(const bnr_exec &x)
     if (!left_looking(x) || !x.overlap || !x.resv || x.shape->gram_kg != 2) return false;
     return x.pipeline == 1;                              // opt-in (notes round 3, B)
 }
-static bnr_gramq gram_queues(const bnr_dev &d)
-{
-    bnr_gramq gq;
-    const int ntl = d.ntile * (d.ntile + 1) / 2;
-    gq.qoff[0] = 0;
-    for (int x = 0; x < 8; ++x) gq.qoff[x + 1] = gq.qoff[x] + ntl * ((d.ksplit - x + 7) / 8);
-    return gq;
-}
+static bool two_panel_default(const bnr_exec &x) { (void)x; return false; }
 static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
 {
     const bnr_dev &d = *x.shape;
@@ -656,9 +669,14 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
     const dim3 ggrid(round_up(ntl * d.ksplit, 8) * x.nb);
     if (x.gram_variant == 9 || (x.gram_variant == 0 && pipelined(x))) {
         const unsigned *resv = pipelined(x) ? x.resv : nullptr;
-        const dim3 pgrid(3 * x.ncu);
-        if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_one>), pgrid, dim3(512), 0, st, bnr_one{d}, s, 1, gram_queues(d), resv, x.gctl);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_many>), pgrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb, gram_queues(d), resv, x.gctl);
+        const dim3 pgrid(BNR_G8P_WPC * x.ncu);
+        if (resv) {
+            if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_one, true>), pgrid, dim3(512), 0, st, bnr_one{d}, s, 1, x.gq, resv, x.gctl);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_many, true>), pgrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb, x.gq, resv, x.gctl);
+        } else {
+            if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_one, false>), pgrid, dim3(512), 0, st, bnr_one{d}, s, 1, x.gq, resv, x.gctl);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_many, false>), pgrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb, x.gq, resv, x.gctl);
+        }
     } else if (d.gram_kg == 4) {
         if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), ggrid, dim3(1024), 0, st, bnr_one{d}, s, 1);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_many, 4>), ggrid, dim3(1024), 0, st, bnr_many{x.cds}, s, x.nb);
@@ -684,6 +702,16 @@ static void launch_rhs(bnr_exec &x, int s) { BNR_LAUNCH(k_rhs, dim3(x.shape->n_p
 static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
 {
     const int nbk = x.shape->n_pad / BNR_NB;
+    if (x.factor_variant == 2 || (x.factor_variant < 0 && two_panel_default(x))) {
+        // two panels per launch (k_chol_step2): half the launches on the critical path, the same arithmetic
+        const int ncu = x.ncu;
+        for (int P = 0; P < nbk / 2; ++P) {
+            const int nsup = bnr_chol2_nsuper(nbk, P), freecu = ncu - x.nb * nbk;
+            const int spw = (freecu > 0 && nbk <= 24 && nsup > 0) ? std::min(4, std::max(1, (x.nb * nsup + freecu - 1) / freecu)) : 1;
+            BNR_LAUNCH(k_chol_step2, dim3(x.nb, nbk + (nsup + spw - 1) / spw), dim3(256), 0, st, x, P, s, spw);
+        }
+        return;
+    }
     if (left_looking(x)) {
         const int nA = (nbk + 3) / 4, nB = nbk - 1;
         for (int p = 0; p < nbk; ++p)
@@ -1030,6 +1058,7 @@ int bnr_group_create(bnr_chain *const *chains, int32_t nchains, bnr_group **out)
     g->m.assign(chains, chains + nchains);
     int rc = exec_init(g->x, chains[0]->device, nchains, &chains[0]->d);
     if (rc) { exec_free(g->x); delete g; return rc; }
+    g->x.gq = chains[0]->x.gq;
     for (bnr_chain *c : g->m) c->group = g;
     *out = g;
     return BNR_OK;
@@ -1093,11 +1122,12 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
         x.gram_variant = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "factor_variant")) {
-        if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "factor_variant must be -1 (auto), 0 (right-looking) or 1 (left-looking)");
+        if (value < -1 || value > 2) return fail(BNR_ERR_BAD_ARG, "factor_variant must be -1 (auto), 0 (right-looking), 1 (left-looking) or 2 (right-looking, two panels per launch)");
         x.factor_variant = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "pipeline")) {
         if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "pipeline must be -1 (auto), 0 or 1");
+        if (value == 1 && !x.resv) x.resv = reserved_cus(x.device, 1);      // the census of compute units runs once per device, only for those who ask
         x.pipeline = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "gate_us")) { if (value < 0 || value > 1000000) return fail(BNR_ERR_BAD_ARG, "gate_us out of range"); x.gate_us = (int)value; drop_graph(x); return BNR_OK; }
@@ -1870,7 +1900,7 @@ static void launch_gram_only(bnr_chain *c)
 {
     const bnr_dev &d = c->d;
     const int ntl = d.ntile * (d.ntile + 1) / 2;
-    if (c->x.gram_variant == 9) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_one>), dim3(3 * c->x.ncu), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1, gram_queues(d), (const unsigned *)nullptr, c->x.gctl);
+    if (c->x.gram_variant == 9) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_one, false>), dim3(BNR_G8P_WPC * c->x.ncu), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1, c->x.gq, (const unsigned *)nullptr, c->x.gctl);
     else if (c->x.gram_variant == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8<bnr_one>), dim3(round_up(ntl * d.ksplit, 8)), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1);
     else if (d.gram_kg == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), dim3(round_up(ntl * d.ksplit, 8)), dim3(1024), 0, c->x.stream, bnr_one{d}, 0, 1);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 2>), dim3(round_up(ntl * d.ksplit, 8)), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1);

@@ -606,6 +606,9 @@ __device__ __forceinline__ void bnr_gstore(double *p, double v)
     if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
+#define BNR_G8P_WPC 2          // persistent Gram workgroups per CU: two (4 waves per SIMD, up to 128 VGPRs).  Three would need the task loop in 80
+                              // VGPRs: the body alone takes 74, the loop's live state spills, and the spill code moved 63 KB of scratch per
+                              // task = 128 MB per 8-chain launch, twice the partial tiles (3.5 x the L2 misses, +40 % on the launch)
 // what a Gram task needs besides the chain's S row and its partial-tile buffer: equal for all members of a lockstep group
 struct bnr_gram_geom { const double *X; int n_pad, q_pad, ksplit, q, ntile; };
 __device__ __forceinline__ bnr_gram_geom bnr_geom_of(const bnr_dev &cd) { return bnr_gram_geom{cd.X, cd.n_pad, cd.q_pad, cd.ksplit, cd.q, cd.ntile}; }
@@ -617,15 +620,16 @@ __device__ __forceinline__ void bnr_setprio3(int level)
     else __builtin_amdgcn_s_setprio(2);
 }
 // one (tile t = (ti, tj), K slice ks) task of the Gram with 8-column batches: 512 threads, sred = 32 KiB of LDS.
-// ROT >= 0 (persistent kernel): the workgroup's issue priority rotates through three levels every 8 batches, phase = ROT = its age
+// ROT >= 0 (persistent kernel): the workgroup's issue priority rotates through BNR_G8P_WPC levels every 16 batches, phase = ROT = its age
 // rank on the CU.  The arbiter serves equal priorities oldest-first, and a persistent workgroup never gets older relative to its
 // two neighbours: without the rotation the eldest runs a task in 61 us, the second in 100, the youngest in 175, and the launch
 // ends with the youngest ones' half-done tasks on an otherwise idle chip.
 template <bool WT>
-__device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const double *Sp, double *Gpart, int t, int ti, int tj, int ks, double *sred, int rot = -1)
+__device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const double *Sp, double *Gpart, int t, int ti, int tj, int ks, double *sred, int rot = -1, int tid = -1)
 {
     constexpr int KG = 2, KB = 8;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (tid < 0) tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
     const int kg = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
     const int kchunk = cd.q_pad / cd.ksplit;          // multiple of 8 KG (host guarantees)
     const int ksub = kchunk / KG;                     // multiple of 8
@@ -634,7 +638,7 @@ __device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const do
     const size_t ld = cd.n_pad;
     const int li = lane & 15, lk = lane >> 4;
     // staging: this thread moves rows (2 rp, 2 rp + 1) of column c of both panels
-    const int tg = threadIdx.x & 255, c = tg >> 5, rp = tg & 31;
+    const int tg = tid & 255, c = tg >> 5, rp = tg & 31;
     // per-lane offsets inside a batch are small (8 columns): 32-bit, so that the loads use the scalar-base + 32-bit-offset form
     const unsigned offI = (unsigned)(ti * BNR_GT + 2 * rp) + (unsigned)c * (unsigned)ld, offJ = (unsigned)(tj * BNR_GT + 2 * rp) + (unsigned)c * (unsigned)ld;
     const double *xb = cd.X + (size_t)eb * ld;
@@ -694,7 +698,7 @@ __device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const do
         // branch in there changes how the compiler interleaves the MFMAs with the LDS reads)
         int b = 0;
         for (int ch = 0; b < nbatch; ++ch) {
-            bnr_setprio3((rot + ch) % 3);
+            bnr_setprio3((rot + ch) % BNR_G8P_WPC);
             const int be = b + 16 < nbatch ? b + 16 : nbatch;
             for (; b < be; ++b) BNR_G8_BATCH(b);
         }
@@ -759,8 +763,10 @@ struct bnr_gramq { int qoff[9]; };                    // queue x = gmapc[qoff[x]
 // next task of a persistent Gram workgroup (ONE wavefront calls this): lanes 0..7 read the eight queue heads (plain loads: a dry
 // queue costs no atomic -- 768 workgroups that each probed every head at the end would queue up ~9 us per word), the first
 // queue with work at or after the own XCD is chosen and ONE atomic takes a ticket from it; -1 when every queue is dry.
-__device__ __forceinline__ void bnr_gram_fetch(unsigned *ctl, const int *s_qlen, unsigned xcc, int lane, int *s_task)
+__device__ __forceinline__ void bnr_gram_fetch(unsigned *ctl, const int *s_qlen, unsigned xcc, int lane_in, int *s_task)
 {
+    int lane;                                          // (opaque copy: nothing derived from it is kept in registers between two calls)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane_in));
     int x = -1, id = 0;
     for (;;) {
         const unsigned head = lane < 8 ? __hip_atomic_load(&ctl[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -776,8 +782,10 @@ __device__ __forceinline__ void bnr_gram_fetch(unsigned *ctl, const int *s_qlen,
     }
     if (lane == 0) { s_task[0] = x; s_task[1] = id; }
 }
-template <class SRC>
-__global__ __launch_bounds__(512, 6) void k_gram8p(const SRC chain_src, int s, int nchains, bnr_gramq gq, const unsigned *resv, unsigned *ctl)
+// PUB: the factorization runs beside this launch: partial tiles written through to the agent's coherence point (sc1) and counted only
+// when every wave's stores have landed; otherwise plain stores (consumed after the kernel boundary: a third of the write traffic)
+template <class SRC, bool PUB>
+__global__ __launch_bounds__(512, 2 * BNR_G8P_WPC) void k_gram8p(const SRC chain_src, int s, int nchains, bnr_gramq gq, const unsigned *resv, unsigned *ctl)
 {
     __shared__ double sred[BNR_GT * BNR_GT];
     __shared__ int s_task[2], s_qlen[8], s_qoff[8], s_ticket;
@@ -810,7 +818,7 @@ __global__ __launch_bounds__(512, 6) void k_gram8p(const SRC chain_src, int s, i
     // a workgroup on a reserved CU leaves at once -- unless it is the last one out of the whole grid: then it finishes what is left
     const bool sweeper = reserved && __builtin_amdgcn_readfirstlane(s_ticket) == (int)gridDim.x - 1;
     if (reserved && !sweeper) return;
-    const int rank = (int)(blockIdx.x / (gridDim.x / 3u)) % 3;        // the dispatcher fills the CUs one workgroup per pass: age rank on the CU
+    const int rank = (int)(blockIdx.x / (gridDim.x / BNR_G8P_WPC)) % BNR_G8P_WPC;   // the dispatcher fills the CUs one workgroup per pass: age rank on the CU
     if (wave == 4) bnr_gram_fetch(ctl, s_qlen, xcc, lane, s_task);
     __syncthreads();
     for (;;) {
@@ -831,8 +839,10 @@ __global__ __launch_bounds__(512, 6) void k_gram8p(const SRC chain_src, int s, i
         {
             const unsigned long long sp_ = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)Sp >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)Sp);
             const unsigned long long gp_ = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)Gp >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)Gp);
+            const unsigned long long pp_ = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)prog >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)prog);
             Sp = (const double *)(__attribute__((address_space(1))) const void *)sp_;
             Gp = (double *)(__attribute__((address_space(1))) void *)gp_;
+            prog = (unsigned int *)(__attribute__((address_space(1))) void *)pp_;
         }
         const int task = __builtin_amdgcn_readfirstlane(gmapc[__builtin_amdgcn_readfirstlane(s_qoff[x]) + id / nchains]);   // wave-uniform: the loop's addressing stays on scalars
         int t = task & 0xFFFF, ti = 0;
@@ -840,11 +850,11 @@ __global__ __launch_bounds__(512, 6) void k_gram8p(const SRC chain_src, int s, i
         while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
         const int tj = t - ti * (ti + 1) / 2;
         __syncthreads();                              // everybody has read s_task
-        bnr_gram8_task<true>(geom, Sp, Gp, t, ti, tj, ks, sred, rank);
+        bnr_gram8_task<PUB>(geom, Sp, Gp, t, ti, tj, ks, sred, rank);
         // K-group 1 is done once its tile is parked: its first wave fetches the next task while K-group 0 adds and stores
         if (wave == 4) bnr_gram_fetch(ctl, s_qlen, xcc, lane, s_task);
         // publish: every wave's write-through stores have landed (vmcnt), then ONE relaxed atomic on the column's counter
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (PUB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_fetch_add(&prog[tj], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1221,6 +1231,255 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
         }
     }
     BNR_STAMP(4);
+}
+
+// ----------------------------------------------------------------------------------------- two panels per launch
+// k_chol_step2(P), P = 0..nbk/2-1: the right-looking factorization of k_chol_step with the panels a = 2P and b = 2P+1 handled by ONE
+// launch -- the same operations on every element in the same order (bitwise the same E), half the launches on the critical
+// path (8 instead of 16 at n = 500: a launch boundary plus the first round trip to L2 cost ~3 us each, and the panel chain is a
+// third of the sweep).
+//   role A (nbk workgroups: matrix block rows >= 2P+2, identity rows 0..2P+1), per workgroup and in this order:
+//     0. blocks (a,a), (b,a), (b,b), (own,a), (own,b) <- pending updates of the panels 2P-2 and 2P-1 (MFMA, fragments from L2);
+//     1. wave 0 sweeps [(a,a) ; (own,a)], wave 1 sweeps [(a,a) ; (b,a)] at the same time (block row b of panel a is needed by
+//        everybody and redone by everybody, like the diagonal block);
+//     2. (b,b) -= L_ba L_ba', (own,b) -= L_own,a L_ba'   (MFMA from LDS: panel a's update of panel b's columns);
+//     3. wave 0 sweeps [(b,b) ; (own,b)].
+//   role B: E[rho,j] -= L[rho,2P-2] L[j,2P-2]' + L[rho,2P-1] L[j,2P-1]' (in that order) for j >= 2P+2: the trailing update of the
+//     previous launch's two panels, beside role A (look-ahead as before).
+struct bnr_panel2_lds {
+    double sDaa[BNR_NB * BNR_LP], sDba[BNR_NB * BNR_LP], sDbb[BNR_NB * BNR_LP], sOa[BNR_NB * BNR_LP], sOb[BNR_NB * BNR_LP];
+    double sCol[2][2][BNR_NB];
+    double sL1[2][16 * BNR_L1S];
+};
+// one half-sweep helper: registers <- LDS panel [D ; B] (lane = row), columns c0..c0+15
+__device__ __forceinline__ void bnr_panel_load16(double (&a)[16], const double *sD, const double *sB, int lane, int c0)
+{
+    const double *src = (lane < 32) ? sD : sB;
+    const int rr = lane & 31;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = src[rr + BNR_LP * (c0 + c)];
+}
+// 16 x 16 tile (columns mt, rows nt) of  C - A B'  with K = 32 from LDS blocks (row + BNR_LP * col): A = rows of `colside`, B = rows of `rowside`
+__device__ __forceinline__ void bnr_lds_tile_update(double *sC, const double *colside, const double *rowside, int mt, int nt, int ln, int lq)
+{
+    bnr_d4 c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = sC[(nt * 16 + ln) + BNR_LP * (mt * 16 + lq + 4 * r)];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(-colside[(mt * 16 + ln) + BNR_LP * (4 * ks + lq)], rowside[(nt * 16 + ln) + BNR_LP * (4 * ks + lq)], c, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sC[(nt * 16 + ln) + BNR_LP * (mt * 16 + lq + 4 * r)] = c[r];
+}
+// second-half update of a swept half panel:  X[rowb.., 16:32] -= L[rowb.., 0:16] L[16:32, 0:16]'  for the 16 rows rowb.. of block sX,
+// L from the 64-row image sL1 (rows 0..31 diagonal block, 32..63 own block); lrow = row of the tile inside sL1
+__device__ __forceinline__ void bnr_mid_tile(double *sX, int rowb, const double *sL1, int lrow, int ln, int lq)
+{
+    bnr_d4 c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = sX[(rowb + ln) + BNR_LP * (16 + lq + 4 * r)];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const double av = sL1[(4 * ks + lq) * BNR_L1S + 16 + ln];            // column side: rows 16..31 of the diagonal part
+        const double bv = sL1[(4 * ks + lq) * BNR_L1S + lrow + ln];          // row side
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av, bv, c, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sX[(rowb + ln) + BNR_LP * (16 + lq + 4 * r)] = c[r];
+}
+__host__ __device__ inline int bnr_chol2_nsuper(int nbk, int P)     // 64 x 64 super blocks of launch P's trailing update
+{
+    if (P == 0) return 0;
+    const int m = nbk - 2 * P - 2, ms = (m + 1) / 2;
+    return m <= 0 ? 0 : ms * (ms + 1) / 2 + ms * P;
+}
+template <class SRC>
+__global__ __launch_bounds__(256, 1) void k_chol_step2(const SRC chain_src, int P, int s, int spw)
+{
+    const bnr_dev &cd = chain_src.get_x();               // grid = (chains, workgroups)
+    __shared__ bnr_panel2_lds sh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nbk = cd.n_pad / BNR_NB;
+    const size_t ld = bnr_ldE(cd.n_pad);
+    const int a = 2 * P, b = a + 1, pa = a * BNR_NB, pb = b * BNR_NB;
+    const int ln = lane & 15, lq = lane >> 4;
+    double *E = cd.E;
+    if ((int)blockIdx.y >= nbk) {
+        // ------------------------------------------------ role B: trailing update with the panels 2P-2 and 2P-1, 64 x 64 super blocks
+        const int m = nbk - 2 * P - 2, ms = (m + 1) / 2, ntri = ms * (ms + 1) / 2, nsup = bnr_chol2_nsuper(nbk, P);
+        for (int u = 0; u < spw; ++u) {
+            int t = ((int)blockIdx.y - nbk) * spw + u, R0, C0;
+            if (t >= nsup) break;
+            bool ident = false;
+            if (t < ntri) {
+                int ti = 0;
+                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+                const int tj = t - ti * (ti + 1) / 2;
+                R0 = a + 2 + 2 * ti; C0 = a + 2 + 2 * tj;
+            } else {
+                t -= ntri;
+                C0 = a + 2 + 2 * (t / P); R0 = nbk + 2 * (t % P);
+                ident = true;
+            }
+            const int rho = R0 + (wave >> 1), j = C0 + (wave & 1);
+            const bool ok = j < nbk && (ident ? (rho - nbk < a) : (rho < nbk && rho >= j));
+            if (!ok) continue;
+            double *cp = E + (size_t)(rho * BNR_NB + ln) + ld * (size_t)(j * BNR_NB + lq);
+            bnr_d4 c[2][2];                                   // [column tile][row tile]
+#pragma unroll
+            for (int at = 0; at < 2; ++at)
+#pragma unroll
+                for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c[at][bt][r] = cp[(size_t)(16 * bt) + ld * (size_t)(16 * at + 4 * r)];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int kc = (a - 2 + qq) * BNR_NB;
+                const double *colrows = E + (size_t)(j * BNR_NB) + ld * (size_t)kc, *rowrows = E + (size_t)(rho * BNR_NB) + ld * (size_t)kc;
+                double av[2][8], bv[2][8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const size_t o = (size_t)ln + ld * (size_t)(4 * ks + lq);
+                    av[0][ks] = colrows[o]; av[1][ks] = colrows[o + 16];
+                    bv[0][ks] = rowrows[o]; bv[1][ks] = rowrows[o + 16];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                    for (int at = 0; at < 2; ++at)
+#pragma unroll
+                        for (int bt = 0; bt < 2; ++bt) c[at][bt] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[at][ks], bv[bt][ks], c[at][bt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int at = 0; at < 2; ++at)
+#pragma unroll
+                for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cp[(size_t)(16 * bt) + ld * (size_t)(16 * at + 4 * r)] = c[at][bt][r];
+        }
+        return;
+    }
+    // ---------------------------------------------------- role A
+    const int bi = blockIdx.y;
+    if (P == 0 && bi == 0) {
+        // cheap safety net for the two-branch schedule: every k_gram_reduce workgroup of THIS sweep must have finished
+        const unsigned int it = cd.plan[cd.pbase[0] + s].it;
+        const int nred = 8 * (cd.ntile * (cd.ntile + 1) / 2);
+        for (int w = tid; w < nred; w += blockDim.x)
+            if (cd.stamp[w] != it) atomicAdd((unsigned long long *)&cd.counters[8], 1ull);
+    }
+    // own block row: matrix rows 2P+2.., then identity rows 0..2P+1
+    const int nmat = nbk - b - 1;
+    const int R = bi < nmat ? b + 1 + bi : nbk + (bi - nmat);
+    const bool only_b = bi >= nmat && (bi - nmat) == b;        // identity row b: block (b, a) of Y is zero and stays zero, only panel b applies
+    {
+        // 0. the five blocks as MFMA tiles (wave = tile: columns mt, rows nt) with the pending updates of the panels 2P-2, 2P-1
+        const int mt = wave >> 1, nt = wave & 1;
+        bnr_d4 cAA, cBA, cBB, cOA, cOB;
+        const size_t orow = (size_t)(nt * 16 + ln), ocol = ld * (size_t)(mt * 16 + lq);
+        const double *pAA = E + (size_t)pa + orow + ld * (size_t)pa + ocol, *pBA = E + (size_t)pb + orow + ld * (size_t)pa + ocol;
+        const double *pBB = E + (size_t)pb + orow + ld * (size_t)pb + ocol;
+        const double *pOA = E + (size_t)(R * BNR_NB) + orow + ld * (size_t)pa + ocol, *pOB = E + (size_t)(R * BNR_NB) + orow + ld * (size_t)pb + ocol;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t o = ld * (size_t)(4 * r);
+            cAA[r] = pAA[o]; cBA[r] = pBA[o]; cBB[r] = pBB[o]; cOA[r] = pOA[o]; cOB[r] = pOB[o];
+        }
+        if (P > 0) {
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const size_t kc = ld * (size_t)((a - 2 + qq) * BNR_NB);
+                // fragments of L[., q]: column sides of block columns a and b (rows mt), row sides of block rows a, b, own (rows nt)
+                double ca[8], cb[8], ra[8], rb[8], ro[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const size_t o = kc + (size_t)ln + ld * (size_t)(4 * ks + lq);
+                    ca[ks] = E[(size_t)(pa + mt * 16) + o]; cb[ks] = E[(size_t)(pb + mt * 16) + o];
+                    ra[ks] = E[(size_t)(pa + nt * 16) + o]; rb[ks] = E[(size_t)(pb + nt * 16) + o];
+                    ro[ks] = E[(size_t)(R * BNR_NB + nt * 16) + o];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    cAA = __builtin_amdgcn_mfma_f64_16x16x4f64(-ca[ks], ra[ks], cAA, 0, 0, 0);
+                    cBA = __builtin_amdgcn_mfma_f64_16x16x4f64(-ca[ks], rb[ks], cBA, 0, 0, 0);
+                    cBB = __builtin_amdgcn_mfma_f64_16x16x4f64(-cb[ks], rb[ks], cBB, 0, 0, 0);
+                    cOA = __builtin_amdgcn_mfma_f64_16x16x4f64(-ca[ks], ro[ks], cOA, 0, 0, 0);
+                    cOB = __builtin_amdgcn_mfma_f64_16x16x4f64(-cb[ks], ro[ks], cOB, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = (nt * 16 + ln) + BNR_LP * (mt * 16 + lq + 4 * r);
+            sh.sDaa[o] = cAA[r]; sh.sDba[o] = cBA[r]; sh.sDbb[o] = cBB[r]; sh.sOa[o] = cOA[r]; sh.sOb[o] = cOB[r];
+        }
+    }
+    __syncthreads();
+    int bad = 0;
+    double a1[16], a2[16];
+    const int rr = lane & 31;
+    // 1. panel a: wave 0 on [Daa ; Oa], wave 1 on [Daa ; Dba]
+    double *sBw = wave == 0 ? sh.sOa : sh.sDba;
+    if (wave < 2) {
+        bnr_panel_load16(a1, sh.sDaa, sBw, lane, 0);
+        bad = bnr_sweep16<0>(a1, lane, sh.sCol[wave]);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sh.sL1[wave][c * BNR_L1S + lane] = a1[c];
+    }
+    __syncthreads();
+    // second halves: the diagonal rows once (waves 0, 1: one tile each), the own rows of the two panels by waves 2 and 3
+    if (wave < 2) bnr_mid_tile(sh.sDaa, wave * 16, sh.sL1[0], wave * 16, ln, lq);
+    else {
+        double *sX = wave == 2 ? sh.sOa : sh.sDba;
+        bnr_mid_tile(sX, 0, sh.sL1[wave - 2], 32, ln, lq);
+        bnr_mid_tile(sX, 16, sh.sL1[wave - 2], 48, ln, lq);
+    }
+    __syncthreads();
+    if (wave < 2) {
+        bnr_panel_load16(a2, sh.sDaa, sBw, lane, 16);
+        bad |= bnr_sweep16<16>(a2, lane, sh.sCol[wave]);
+        if (lane >= 32) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { sBw[rr + BNR_LP * c] = a1[c]; sBw[rr + BNR_LP * (16 + c)] = a2[c]; }
+        }
+    }
+    __syncthreads();
+    // 2. panel a's update of panel b's columns:  Dbb -= L_ba L_ba',  Ob -= L_own,a L_ba'   (two tiles per wave)
+    {
+        const int mt = wave >> 1, nt = wave & 1;
+        bnr_lds_tile_update(sh.sDbb, sh.sDba, sh.sDba, mt, nt, ln, lq);
+        bnr_lds_tile_update(sh.sOb, sh.sDba, sh.sOa, mt, nt, ln, lq);
+    }
+    __syncthreads();
+    // 3. panel b: wave 0 on [Dbb ; Ob], the second half updated by all four waves
+    if (wave == 0) {
+        bnr_panel_load16(a1, sh.sDbb, sh.sOb, lane, 0);
+        bad |= bnr_sweep16<0>(a1, lane, sh.sCol[0]);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sh.sL1[0][c * BNR_L1S + lane] = a1[c];
+    }
+    __syncthreads();
+    bnr_mid_tile(wave < 2 ? sh.sDbb : sh.sOb, (wave & 1) * 16, sh.sL1[0], 16 * wave, ln, lq);
+    __syncthreads();
+    if (wave == 0) {
+        bnr_panel_load16(a2, sh.sDbb, sh.sOb, lane, 16);
+        bad |= bnr_sweep16<16>(a2, lane, sh.sCol[0]);
+        if (lane >= 32) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { sh.sOb[rr + BNR_LP * c] = a1[c]; sh.sOb[rr + BNR_LP * (16 + c)] = a2[c]; }
+        }
+    }
+    __syncthreads();
+    if (bad && tid == 0 && bi == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[7], 1ull); }
+    // the swept own blocks; the diagonal blocks and block row b of panel a are needed by nobody later
+    {
+        const int r = tid & 31, c0 = tid >> 5;
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            const int c = c0 + 8 * mm;
+            if (!only_b) E[(size_t)(R * BNR_NB + r) + ld * (size_t)(pa + c)] = sh.sOa[r + BNR_LP * c];
+            E[(size_t)(R * BNR_NB + r) + ld * (size_t)(pb + c)] = sh.sOb[r + BNR_LP * c];
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------- left-looking factorization

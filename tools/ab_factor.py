@@ -31,10 +31,10 @@ def tables(n, V, R, variant, rows=6, extra=None):
     return out
 
 bad = 0
-for (n, V, R) in [(70, 19, 5), (500, 100, 7), (130, 12, 3), (64, 9, 2), (193, 30, 5), (1, 5, 2), (33, 2, 1), (1000, 40, 4)]:
+for (n, V, R) in [(70, 19, 5), (500, 100, 7), (130, 12, 3), (64, 9, 2), (193, 30, 5), (1, 5, 2), (33, 2, 1), (1000, 40, 4), (2000, 12, 3)]:
     t0 = tables(n, V, R, 0)
-    for name, extra in (("left", {"pipeline": 0}), ("left+persistent gram", {"pipeline": 0, "gram_variant": 9}), ("pipelined", {"pipeline": 1})):
-        t1 = tables(n, V, R, 1, extra=extra)
+    for name, fv, extra in (("two panels per launch", 2, {}), ("left", 1, {"pipeline": 0}), ("left+persistent gram", 1, {"pipeline": 0, "gram_variant": 9}), ("pipelined", 1, {"pipeline": 1})):
+        t1 = tables(n, V, R, fv, extra=extra)
         for k in bo.COLUMNS:
             for i, what in ((0, "group"), (1, "alone")):
                 if not np.array_equal(t0[i][k], t1[i][k], equal_nan=True):
@@ -47,7 +47,7 @@ print("mismatches:", bad)
 
 # timing at the headline size, 8 chains
 X, y, _ = bnr_amd.make_synthetic(500, 100, 7, seed=20240501)
-for variant, pipe in ((0, 0), (1, 0), (1, 1)):
+for variant, pipe in ((0, 0), (2, 0), (1, 0)):
     tot = 1500
     ch = bnr_amd.Chain(X, y, 7, tot, 5, 1)
     members = [ch] + [bnr_amd.Chain.like(ch, 5, c, tot) for c in range(2, 9)]
