@@ -526,8 +526,6 @@ static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape)
     }
     HIPCHK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&x.stream2, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&x.stream3, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&x.stream4, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void **)&x.gctl, 64));
     HIPCHK(hipMemset(x.gctl, 0, 64));
     HIPCHK(hipMalloc((void **)&x.cds, sizeof(bnr_dev) * nb));
@@ -646,8 +644,8 @@ static bool left_looking(const bnr_exec &x)
 // CUs, k_chol_ll's gates follow its progress column by column); otherwise it follows the Gram on the same stream.
 static bool pipelined(const bnr_exec &x)
 {
-    if (!left_looking(x) || !x.overlap || !x.resv || x.shape->gram_kg != 2) return false;
-    return x.pipeline == 1;                              // opt-in (notes round 3, B)
+    if (!left_looking(x) || !x.overlap || x.shape->gram_kg != 2) return false;
+    return x.pipeline == 1 && x.resv;                              // opt-in (notes round 3, B)
 }
 static bool two_panel_default(const bnr_exec &x) { (void)x; return false; }
 static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
@@ -1113,6 +1111,21 @@ int bnr_group_run(bnr_group *g, int32_t first_index, int32_t nburn, int32_t tota
     return rc;
 }
 
+// the extra streams of the opt-in pipelined schedules are created when somebody asks for one (the default path creates nothing new)
+static int ensure_pipeline_streams(bnr_exec &x, int mode)
+{
+    HIPCHK(hipSetDevice(x.device));
+    if (!x.stream3) {
+        // the factorization branch on a HIGH-priority queue (it did not help against a many-round Gram that has workgroups waiting for a
+        // slot -- the dispatcher does not get round to other queues until the grid is dispatched -- but it does no harm either)
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
+        HIPCHK(hipStreamCreateWithPriority(&x.stream3, hipStreamNonBlocking, hi));
+    }
+    if (!x.stream4) HIPCHK(hipStreamCreateWithFlags(&x.stream4, hipStreamNonBlocking));
+    if (mode == 1 && !x.resv) x.resv = reserved_cus(x.device, 1);          // the census of compute units runs once per device, only for those who ask
+    return BNR_OK;
+}
 static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
 {
     if (!strcmp(name, "graph")) { x.use_graph = (int)value; return BNR_OK; }
@@ -1127,7 +1140,7 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
     }
     if (!strcmp(name, "pipeline")) {
         if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "pipeline must be -1 (auto), 0 or 1");
-        if (value == 1 && !x.resv) x.resv = reserved_cus(x.device, 1);      // the census of compute units runs once per device, only for those who ask
+        if (value > 0) { int rc = ensure_pipeline_streams(x, (int)value); if (rc) return rc; }
         x.pipeline = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "gate_us")) { if (value < 0 || value > 1000000) return fail(BNR_ERR_BAD_ARG, "gate_us out of range"); x.gate_us = (int)value; drop_graph(x); return BNR_OK; }

@@ -468,28 +468,31 @@ __device__ __forceinline__ void bnr_gram_count(const bnr_dev &cd, int tj)
 // Grid (1-D) = round_up(tasks, 8) x chains.  Workgroup id -> XCD label id % 8 (round-robin dispatch), and within one
 // XCD's sequence the chains of a lockstep group are innermost: the 8 (or C) workgroups that need the same panels of X
 // (same tile, same K slice, different S) run next to each other on the same XCD and share them through its L2.
-template <class SRC, int KG>
-__global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, int s, int nchains)
+// a partial-tile element goes to memory either as a plain store (consumed after the kernel boundary) or written through to the
+// agent's coherence point (sc1), for a consumer that runs beside this kernel on another XCD
+template <bool WT>
+__device__ __forceinline__ void bnr_gstore(double *p, double v)
 {
-    const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
-    const int gchain = gr % nchains, gslot = (gr / nchains) * 8 + gx;      // gslot: position in the one-chain task map
-    const bnr_dev &cd = chain_src.at(gchain);
-    __shared__ double sred[KG * BNR_GT * BNR_GT];     // staging buffers during the loop, then the K-group reduction
-    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
-    const double *Sp = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
-#ifdef BNR_STAMPS
-#define BNR_GSTAMP(slot) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 251)) { int o_ = 400 + 8 * (blockIdx.x == 0 ? 0 : (blockIdx.x == 100 ? 1 : 2)) + (slot); cd.dbg[o_] = __builtin_amdgcn_s_memtime(); cd.dbg[o_ + 4] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#else
-#define BNR_GSTAMP(slot) do { } while (0)
-#endif
-    BNR_GSTAMP(0);
-    // the task map's extent is padded to a multiple of 8 so that id % 8 labels the XCD
-    if (gslot >= cd.ksplit * (cd.ntile * (cd.ntile + 1) / 2)) return;
-    const int task = cd.gmap[gslot];
-    int t = task & 0xFFFF, ti = 0;
-    const int ks = task >> 16;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    int tj = t - ti * (ti + 1) / 2;
+    if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+#define BNR_G8P_WPC 2          // persistent Gram workgroups per CU: two (4 waves per SIMD, up to 128 VGPRs).  Three would need the task loop in 80
+                              // VGPRs: the body alone takes 74, the loop's live state spills, and the spill code moved 63 KB of scratch per
+                              // task = 128 MB per 8-chain launch, twice the partial tiles (3.5 x the L2 misses, +40 % on the launch)
+// what a Gram task needs besides the chain's S row and its partial-tile buffer: equal for all members of a lockstep group
+struct bnr_gram_geom { const double *X; int n_pad, q_pad, ksplit, q, ntile; };
+__device__ __forceinline__ bnr_gram_geom bnr_geom_of(const bnr_dev &cd) { return bnr_gram_geom{cd.X, cd.n_pad, cd.q_pad, cd.ksplit, cd.q, cd.ntile}; }
+// s_setprio takes an immediate: a wave-uniform level 0..2
+__device__ __forceinline__ void bnr_setprio3(int level)
+{
+    if (level == 0) __builtin_amdgcn_s_setprio(0);
+    else if (level == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(2);
+}
+// one (tile t = (ti, tj), K slice ks) task of the Gram with 16-column batches: KG x 256 threads, sred = KG x 32 KiB of LDS
+template <int KG, bool WT>
+__device__ __forceinline__ void bnr_gram16_task(const bnr_gram_geom &cd, const double *Sp, double *Gpart, int t, int ti, int tj, int ks, double *sred, int rot = -1)
+{
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kg = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
     const int kchunk = cd.q_pad / cd.ksplit;          // multiple of 8 KG (host guarantees)
@@ -555,8 +558,8 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
     BNR_GRAM_STORE(0);
     BNR_GRAM_LOAD(1);
     __syncthreads();
-    BNR_GSTAMP(1);
     for (int b = 0; b < nfull; ++b) {
+        if (rot >= 0 && (b & 7) == 0) bnr_setprio3((rot + (b >> 3)) % BNR_G8P_WPC);
         // first half of the batch, then the staging work of the next one, then the second half: the wait for the loads
         // issued one batch ago and the LDS writes sit behind 8 MFMAs already in flight (measured: +4 % over staging first)
         BNR_GRAM_COMPUTE(b & 1, 0, 2);
@@ -567,7 +570,6 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
     }
     if (half) { BNR_GRAM_COMPUTE(nfull & 1, 0, 2); __syncthreads(); }
     (void)nbatch;
-    BNR_GSTAMP(2);
     // tile element (i,j) lives at [j*64 + i]; this lane: j = wj*32 + jt*16 + (lane>>4) + 4 r, i = wi*32 + it*16 + (lane&15)
     double *mine = sred + (size_t)kg * (BNR_GT * BNR_GT);
     const int jb = wj * 32 + (lane >> 4), ib = wi * 32 + (lane & 15);
@@ -579,13 +581,30 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
         mine[(jb + 16 + 4 * r) * BNR_GT + ib + 16] = c11[r];
     }
     __syncthreads();
-    double *out = cd.Gpart + ((size_t)ks * (cd.ntile * (cd.ntile + 1) / 2) + t) * (BNR_GT * BNR_GT);
+    double *out = Gpart + ((size_t)ks * (cd.ntile * (cd.ntile + 1) / 2) + t) * (BNR_GT * BNR_GT);
 #pragma unroll
     for (int idx = threadIdx.x; idx < BNR_GT * BNR_GT; idx += KG * 256) {
-        if (KG == 4) out[idx] = (sred[idx] + sred[BNR_GT * BNR_GT + idx]) + (sred[2 * BNR_GT * BNR_GT + idx] + sred[3 * BNR_GT * BNR_GT + idx]);
-        else out[idx] = sred[idx] + sred[BNR_GT * BNR_GT + idx];
+        if (KG == 4) bnr_gstore<WT>(out + idx, (sred[idx] + sred[BNR_GT * BNR_GT + idx]) + (sred[2 * BNR_GT * BNR_GT + idx] + sred[3 * BNR_GT * BNR_GT + idx]));
+        else bnr_gstore<WT>(out + idx, sred[idx] + sred[BNR_GT * BNR_GT + idx]);
     }
-    BNR_GSTAMP(3);
+}
+template <class SRC, int KG>
+__global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, int s, int nchains)
+{
+    const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
+    const int gchain = gr % nchains, gslot = (gr / nchains) * 8 + gx;      // gslot: position in the one-chain task map
+    const bnr_dev &cd = chain_src.at(gchain);
+    __shared__ double sred[KG * BNR_GT * BNR_GT];     // staging buffers during the loop, then the K-group reduction
+    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
+    const double *Sp = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
+    // the task map's extent is padded to a multiple of 8 so that id % 8 labels the XCD
+    if (gslot >= cd.ksplit * (cd.ntile * (cd.ntile + 1) / 2)) return;
+    const int task = cd.gmap[gslot];
+    int t = task & 0xFFFF, ti = 0;
+    const int ks = task >> 16;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    int tj = t - ti * (ti + 1) / 2;
+    bnr_gram16_task<KG, false>(bnr_geom_of(cd), Sp, cd.Gpart, t, ti, tj, ks, sred);
     bnr_gram_count(cd, tj);
 }
 
@@ -598,27 +617,6 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
 // 2 K-groups x 2 buffers x [I | J] x 8 x 64 doubles; a barrier per 8 MFMAs of a wave), with a K-group reduction that needs one tile
 // of LDS instead of two (K-group 1 parks its tile, K-group 0 adds its registers and stores).  Eight waves per SIMD (64 VGPRs through
 // buffer descriptors) brought nothing more (profiles/round2_experiments_notes.txt D).
-// a partial-tile element goes to memory either as a plain store (consumed after the kernel boundary) or written through to the
-// agent's coherence point (sc1), for a consumer that runs beside this kernel on another XCD
-template <bool WT>
-__device__ __forceinline__ void bnr_gstore(double *p, double v)
-{
-    if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-#define BNR_G8P_WPC 2          // persistent Gram workgroups per CU: two (4 waves per SIMD, up to 128 VGPRs).  Three would need the task loop in 80
-                              // VGPRs: the body alone takes 74, the loop's live state spills, and the spill code moved 63 KB of scratch per
-                              // task = 128 MB per 8-chain launch, twice the partial tiles (3.5 x the L2 misses, +40 % on the launch)
-// what a Gram task needs besides the chain's S row and its partial-tile buffer: equal for all members of a lockstep group
-struct bnr_gram_geom { const double *X; int n_pad, q_pad, ksplit, q, ntile; };
-__device__ __forceinline__ bnr_gram_geom bnr_geom_of(const bnr_dev &cd) { return bnr_gram_geom{cd.X, cd.n_pad, cd.q_pad, cd.ksplit, cd.q, cd.ntile}; }
-// s_setprio takes an immediate: a wave-uniform level 0..2
-__device__ __forceinline__ void bnr_setprio3(int level)
-{
-    if (level == 0) __builtin_amdgcn_s_setprio(0);
-    else if (level == 1) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(2);
-}
 // one (tile t = (ti, tj), K slice ks) task of the Gram with 8-column batches: 512 threads, sred = 32 KiB of LDS.
 // ROT >= 0 (persistent kernel): the workgroup's issue priority rotates through BNR_G8P_WPC levels every 16 batches, phase = ROT = its age
 // rank on the CU.  The arbiter serves equal priorities oldest-first, and a persistent workgroup never gets older relative to its
@@ -726,6 +724,7 @@ __device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const do
         }
     }
 }
+struct bnr_gramq { int qoff[9]; };                    // per-XCD task list x = gmapc[qoff[x] .. qoff[x+1])
 template <class SRC>
 __global__ __launch_bounds__(512, 6) void k_gram8(const SRC chain_src, int s, int nchains)
 {
@@ -759,7 +758,6 @@ __global__ __launch_bounds__(512, 6) void k_gram8(const SRC chain_src, int s, in
 //   ctl (device words, zero between launches): [0..7] queue heads, [8] tickets.
 __device__ __forceinline__ unsigned bnr_hw_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v)); return v; }
 __device__ __forceinline__ unsigned bnr_xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 7u; }
-struct bnr_gramq { int qoff[9]; };                    // queue x = gmapc[qoff[x] .. qoff[x+1])
 // next task of a persistent Gram workgroup (ONE wavefront calls this): lanes 0..7 read the eight queue heads (plain loads: a dry
 // queue costs no atomic -- 768 workgroups that each probed every head at the end would queue up ~9 us per word), the first
 // queue with work at or after the own XCD is chosen and ONE atomic takes a ticket from it; -1 when every queue is dry.
@@ -783,12 +781,15 @@ __device__ __forceinline__ void bnr_gram_fetch(unsigned *ctl, const int *s_qlen,
     if (lane == 0) { s_task[0] = x; s_task[1] = id; }
 }
 // PUB: the factorization runs beside this launch: partial tiles written through to the agent's coherence point (sc1) and counted only
-// when every wave's stores have landed; otherwise plain stores (consumed after the kernel boundary: a third of the write traffic)
+// when every wave's stores have landed; otherwise plain stores (consumed after the kernel boundary).
+// Two workgroups per CU with the 16-column body of k_gram (64 KiB of LDS, up to 128 VGPRs): three per CU would need the task loop in 80
+// VGPRs -- the 8-column body alone takes 74, the loop's live state then spills, and the spill code moved 63 KB of scratch per task = 128 MB
+// per 8-chain launch, twice the partial tiles (3.5 x the L2 misses, +40 % on the launch; profiles/round3_experiments_notes.txt B.2).
 template <class SRC, bool PUB>
 __global__ __launch_bounds__(512, 2 * BNR_G8P_WPC) void k_gram8p(const SRC chain_src, int s, int nchains, bnr_gramq gq, const unsigned *resv, unsigned *ctl)
 {
-    __shared__ double sred[BNR_GT * BNR_GT];
-    __shared__ int s_task[2], s_qlen[8], s_qoff[8], s_ticket;
+    __shared__ double sred[2 * BNR_GT * BNR_GT];
+    __shared__ int s_task[4], s_qlen[8], s_qoff[8], s_ticket;             // s_task: {queue, id} of the current and of the next task
     // per member: the S row of this sweep, the partial-tile buffer, the progress words -- read once per workgroup, so that a task
     // starts from two LDS reads instead of a chain of dependent global loads (descriptor -> plan entry -> row)
     constexpr int TABMAX = 64;
@@ -819,10 +820,10 @@ __global__ __launch_bounds__(512, 2 * BNR_G8P_WPC) void k_gram8p(const SRC chain
     const bool sweeper = reserved && __builtin_amdgcn_readfirstlane(s_ticket) == (int)gridDim.x - 1;
     if (reserved && !sweeper) return;
     const int rank = (int)(blockIdx.x / (gridDim.x / BNR_G8P_WPC)) % BNR_G8P_WPC;   // the dispatcher fills the CUs one workgroup per pass: age rank on the CU
-    if (wave == 4) bnr_gram_fetch(ctl, s_qlen, xcc, lane, s_task);
+    if (wave == 7) bnr_gram_fetch(ctl, s_qlen, xcc, lane, s_task);
     __syncthreads();
-    for (;;) {
-        const int x = __builtin_amdgcn_readfirstlane(s_task[0]), id = __builtin_amdgcn_readfirstlane(s_task[1]);
+    for (int cur = 0;; cur ^= 2) {
+        const int x = __builtin_amdgcn_readfirstlane(s_task[cur]), id = __builtin_amdgcn_readfirstlane(s_task[cur + 1]);
         if (x < 0) break;
         const int member = id % nchains;
         const double *Sp;
@@ -849,10 +850,10 @@ __global__ __launch_bounds__(512, 2 * BNR_G8P_WPC) void k_gram8p(const SRC chain
         const int ks = task >> 16;
         while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
         const int tj = t - ti * (ti + 1) / 2;
-        __syncthreads();                              // everybody has read s_task
-        bnr_gram8_task<PUB>(geom, Sp, Gp, t, ti, tj, ks, sred, rank);
-        // K-group 1 is done once its tile is parked: its first wave fetches the next task while K-group 0 adds and stores
-        if (wave == 4) bnr_gram_fetch(ctl, s_qlen, xcc, lane, s_task);
+        // the NEXT task is fetched now, by the last wave, behind the first loads of this one (two dependent round trips that would
+        // otherwise sit between two tasks)
+        if (wave == 7) bnr_gram_fetch(ctl, s_qlen, xcc, lane, s_task + (cur ^ 2));
+        bnr_gram16_task<2, PUB>(geom, Sp, Gp, t, ti, tj, ks, sred, rank);
         // publish: every wave's write-through stores have landed (vmcnt), then ONE relaxed atomic on the column's counter
         if (PUB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -8,7 +8,7 @@ tot = 1300
 configs = [("graph, right-looking (round 2)", {"factor_variant": 0, "pipeline": 0, "graph": 1}),
            ("eager, right-looking", {"factor_variant": 0, "pipeline": 0, "graph": 0}),
            ("eager, left-looking after the Gram", {"factor_variant": 1, "pipeline": 0, "graph": 0}),
-           ("eager, left-looking BESIDE the Gram on a CU-masked stream", {"factor_variant": 1, "pipeline": 2, "graph": 0})]
+           ("graph, left-looking BESIDE the persistent Gram", {"factor_variant": 1, "pipeline": 1, "graph": 1})]
 ref = None
 for name, opts in configs:
     ch = bnr_amd.Chain(X, y, 7, tot, 5, 1)
