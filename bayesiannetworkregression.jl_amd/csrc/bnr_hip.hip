@@ -53,6 +53,7 @@ struct bnr_exec {
     size_t fj_next = 0;
     int overlap = 1;
     int gram_variant = 0;                               // 0: chosen per launch; 8 / 16: k_gram8 / k_gram forced (tests, experiments)
+    int spw_cap = 4;                                    // super blocks per update workgroup of the factorization, at most
     int factor_variant = -1;                            // -1: chosen by size; 0: right-looking k_chol_step (+ k_gram_reduce); 1: left-looking k_chol_ll
     int use_graph = 1, graph_k = 8;
     struct rung { int k; hipGraph_t graph; hipGraphExec_t gexec; };
@@ -647,7 +648,9 @@ static bool pipelined(const bnr_exec &x)
     if (!left_looking(x) || !x.overlap || x.shape->gram_kg != 2) return false;
     return x.pipeline == 1 && x.resv;                              // opt-in (notes round 3, B)
 }
-static bool two_panel_default(const bnr_exec &x) { (void)x; return false; }
+// two panels per launch with the K = 128 trailing update (variant 3) where the trailing update is bandwidth-bound: n_pad >= 1024
+// (n = 2000 one chain 424 -> 448 it/s, n = 1000 eight chains 5.49 -> 5.88 k it/s; at n = 500 it is a draw and the one-panel launches stay)
+static bool two_panel_default(const bnr_exec &x) { return x.shape->n_pad >= 1024; }
 static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
 {
     const bnr_dev &d = *x.shape;
@@ -700,13 +703,14 @@ static void launch_rhs(bnr_exec &x, int s) { BNR_LAUNCH(k_rhs, dim3(x.shape->n_p
 static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
 {
     const int nbk = x.shape->n_pad / BNR_NB;
-    if (x.factor_variant == 2 || (x.factor_variant < 0 && two_panel_default(x))) {
-        // two panels per launch (k_chol_step2): half the launches on the critical path, the same arithmetic
-        const int ncu = x.ncu;
+    if (x.factor_variant == 2 || x.factor_variant == 3 || (x.factor_variant < 0 && two_panel_default(x))) {
+        // two panels per launch (k_chol_step2): half the launches on the critical path, the same arithmetic; variant 3 (the choice for
+        // large n): the whole trailing matrix is read and written at every other launch only, with K = 128
+        const int ncu = x.ncu, lazy = x.factor_variant != 2;
         for (int P = 0; P < nbk / 2; ++P) {
-            const int nsup = bnr_chol2_nsuper(nbk, P), freecu = ncu - x.nb * nbk;
-            const int spw = (freecu > 0 && nbk <= 24 && nsup > 0) ? std::min(4, std::max(1, (x.nb * nsup + freecu - 1) / freecu)) : 1;
-            BNR_LAUNCH(k_chol_step2, dim3(x.nb, nbk + (nsup + spw - 1) / spw), dim3(256), 0, st, x, P, s, spw);
+            const int nsup = bnr_chol2_nsuper(nbk, P, lazy), freecu = ncu - x.nb * nbk;
+            const int spw = (freecu > 0 && nbk <= 24 && nsup > 0) ? std::min(x.spw_cap, std::max(1, (x.nb * nsup + freecu - 1) / freecu)) : 1;
+            BNR_LAUNCH(k_chol_step2, dim3(x.nb, nbk + (nsup + spw - 1) / spw), dim3(256), 0, st, x, P, s, spw, lazy);
         }
         return;
     }
@@ -728,7 +732,7 @@ static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
             // free (at most 4: they must stay shorter than a panel sweep; only while E is L2-sized -- for large n the update is
             // bandwidth-bound and wants every workgroup in flight at once: n=2000 408 vs 421 it/s)
             const int freecu = ncu - x.nb * npan;
-            const int spw = (freecu > 0 && nbk <= 24) ? std::min(4, std::max(1, (x.nb * nsup + freecu - 1) / freecu)) : 1;
+            const int spw = (freecu > 0 && nbk <= 24) ? std::min(x.spw_cap, std::max(1, (x.nb * nsup + freecu - 1) / freecu)) : 1;
             BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + (nsup + spw - 1) / spw), dim3(256), 0, st, x, p, s, 0, spw);
         } else {
             BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + ntile), dim3(256), 0, st, x, p, s, 1, 1);
@@ -1134,8 +1138,12 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
         if (value != 0 && value != 8 && value != 9 && value != 16) return fail(BNR_ERR_BAD_ARG, "gram_variant must be 0 (auto), 8, 9 (persistent) or 16");
         x.gram_variant = (int)value; drop_graph(x); return BNR_OK;
     }
+    if (!strcmp(name, "spw_cap")) {
+        if (value < 1 || value > 4) return fail(BNR_ERR_BAD_ARG, "spw_cap must be 1..4");
+        x.spw_cap = (int)value; drop_graph(x); return BNR_OK;
+    }
     if (!strcmp(name, "factor_variant")) {
-        if (value < -1 || value > 2) return fail(BNR_ERR_BAD_ARG, "factor_variant must be -1 (auto), 0 (right-looking), 1 (left-looking) or 2 (right-looking, two panels per launch)");
+        if (value < -1 || value > 3) return fail(BNR_ERR_BAD_ARG, "factor_variant must be -1 (auto), 0 (right-looking), 1 (left-looking), 2 (right-looking, two panels per launch) or 3 (2 with the K = 128 trailing update)");
         x.factor_variant = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "pipeline")) {

@@ -1160,6 +1160,9 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
 #pragma unroll
                         for (int r = 0; r < 4; ++r) cp[(size_t)(16 * b) + ld * (size_t)(16 * a + 4 * r)] = c[a][b][r];
             }
+#ifdef BNR_STAMPS
+            if (tid == 0) atomicMax((unsigned long long *)&cd.dbg[p * 8 + 7], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
             return;
         }
         // few blocks: tpw of them per workgroup, each wave one 16 x 16 tile of every block
@@ -1185,6 +1188,9 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
 #pragma unroll
             for (int r = 0; r < 4; ++r) cp[ld * (size_t)(4 * r)] = c[r];
         }
+#ifdef BNR_STAMPS
+        if (tid == 0) atomicMax((unsigned long long *)&cd.dbg[p * 8 + 7], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
         return;
     }
     // ---------------------------------------------------- role A: panel workgroup
@@ -1202,6 +1208,13 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
 #define BNR_STAMP(slot) do { } while (0)
 #endif
     BNR_STAMP(0);
+#ifdef BNR_STAMPS
+    if (tid == 0) {                                        // s_memrealtime (100 MHz, the same on every XCD): slot 1 = start of panel workgroup 0, 6 = latest panel start, 5 / 7 = latest panel / update end (tools/stamps_spread.py)
+        const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+        if (b == 0) cd.dbg[p * 8 + 1] = rt;
+        atomicMax((unsigned long long *)&cd.dbg[p * 8 + 6], rt);
+    }
+#endif
     int rho;                                               // own block row
     if (b < nbk - p) rho = p + b;                          // matrix rows p..nbk-1
     else rho = nbk + (b - (nbk - p));                      // identity block rows 0..p
@@ -1232,6 +1245,9 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
         }
     }
     BNR_STAMP(4);
+#ifdef BNR_STAMPS
+    if (tid == 0) atomicMax((unsigned long long *)&cd.dbg[p * 8 + 5], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 // ----------------------------------------------------------------------------------------- two panels per launch
@@ -1288,14 +1304,60 @@ __device__ __forceinline__ void bnr_mid_tile(double *sX, int rowb, const double 
 #pragma unroll
     for (int r = 0; r < 4; ++r) sX[(rowb + ln) + BNR_LP * (16 + lq + 4 * r)] = c[r];
 }
-__host__ __device__ inline int bnr_chol2_nsuper(int nbk, int P)     // 64 x 64 super blocks of launch P's trailing update
+// lazy = 1 (variant 3): the read-modify-write of the whole trailing matrix happens at the ODD launches only, with the four panels of the
+// two launches before (K = 128); an EVEN launch only brings the next launch's two panel columns up to date (panels of the launch
+// before, K = 64).  Every element still sees the panels in ascending order, eight MFMA k-steps each: bitwise the same E with half the
+// trailing traffic.
+__host__ __device__ inline int bnr_chol2_nsuper(int nbk, int P, int lazy = 0)     // 64 x 64 super blocks of launch P's trailing update
 {
     if (P == 0) return 0;
     const int m = nbk - 2 * P - 2, ms = (m + 1) / 2;
-    return m <= 0 ? 0 : ms * (ms + 1) / 2 + ms * P;
+    if (m <= 0) return 0;
+    if (lazy && !(P & 1)) return ms + P;                 // the super column of the next launch's panels only
+    return ms * (ms + 1) / 2 + ms * P;
+}
+// One wave's 32 x 32 block (rho, j) of the trailing matrix <- - sum over the NQ pending panels q0.. of L[rho,q] L[j,q]' (ascending q, eight MFMA
+// k-steps each); the block and all NQ panels' fragments are requested before the first MFMA.
+template <int NQ>
+__device__ __forceinline__ void bnr_super_update(double *E, size_t ld, int rho, int j, int q0, int ln, int lq)
+{
+    double *cp = E + (size_t)(rho * BNR_NB + ln) + ld * (size_t)(j * BNR_NB + lq);
+    bnr_d4 c[2][2];                                   // [column tile][row tile]
+#pragma unroll
+    for (int at = 0; at < 2; ++at)
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[at][bt][r] = cp[(size_t)(16 * bt) + ld * (size_t)(16 * at + 4 * r)];
+    double av[NQ][2][8], bv[NQ][2][8];
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+        const int kc = (q0 + qq) * BNR_NB;
+        const double *colrows = E + (size_t)(j * BNR_NB) + ld * (size_t)kc, *rowrows = E + (size_t)(rho * BNR_NB) + ld * (size_t)kc;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const size_t o = (size_t)ln + ld * (size_t)(4 * ks + lq);
+            av[qq][0][ks] = colrows[o]; av[qq][1][ks] = colrows[o + 16];
+            bv[qq][0][ks] = rowrows[o]; bv[qq][1][ks] = rowrows[o + 16];
+        }
+    }
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int at = 0; at < 2; ++at)
+#pragma unroll
+                for (int bt = 0; bt < 2; ++bt) c[at][bt] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[qq][at][ks], bv[qq][bt][ks], c[at][bt], 0, 0, 0);
+#pragma unroll
+    for (int at = 0; at < 2; ++at)
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cp[(size_t)(16 * bt) + ld * (size_t)(16 * at + 4 * r)] = c[at][bt][r];
 }
 template <class SRC>
-__global__ __launch_bounds__(256, 1) void k_chol_step2(const SRC chain_src, int P, int s, int spw)
+__global__ __launch_bounds__(256, 1) void k_chol_step2(const SRC chain_src, int P, int s, int spw, int lazy)
 {
     const bnr_dev &cd = chain_src.get_x();               // grid = (chains, workgroups)
     __shared__ bnr_panel2_lds sh;
@@ -1306,15 +1368,21 @@ __global__ __launch_bounds__(256, 1) void k_chol_step2(const SRC chain_src, int 
     double *E = cd.E;
     if ((int)blockIdx.y >= nbk) {
         // ------------------------------------------------ role B: trailing update with the panels 2P-2 and 2P-1, 64 x 64 super blocks
-        const int m = nbk - 2 * P - 2, ms = (m + 1) / 2, ntri = ms * (ms + 1) / 2, nsup = bnr_chol2_nsuper(nbk, P);
+        const int m = nbk - 2 * P - 2, ms = (m + 1) / 2, nsup = bnr_chol2_nsuper(nbk, P, lazy);
+        const bool near = lazy && !(P & 1);
+        const int ntri = near ? ms : ms * (ms + 1) / 2;
+        const int q0 = (lazy && (P & 1) && a >= 4) ? a - 4 : a - 2, nq = a - q0;      // pending panels q0 .. a-1
         for (int u = 0; u < spw; ++u) {
             int t = ((int)blockIdx.y - nbk) * spw + u, R0, C0;
             if (t >= nsup) break;
             bool ident = false;
             if (t < ntri) {
-                int ti = 0;
-                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-                const int tj = t - ti * (ti + 1) / 2;
+                int ti = 0, tj = 0;
+                if (near) ti = t;
+                else {
+                    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+                    tj = t - ti * (ti + 1) / 2;
+                }
                 R0 = a + 2 + 2 * ti; C0 = a + 2 + 2 * tj;
             } else {
                 t -= ntri;
@@ -1324,38 +1392,8 @@ __global__ __launch_bounds__(256, 1) void k_chol_step2(const SRC chain_src, int 
             const int rho = R0 + (wave >> 1), j = C0 + (wave & 1);
             const bool ok = j < nbk && (ident ? (rho - nbk < a) : (rho < nbk && rho >= j));
             if (!ok) continue;
-            double *cp = E + (size_t)(rho * BNR_NB + ln) + ld * (size_t)(j * BNR_NB + lq);
-            bnr_d4 c[2][2];                                   // [column tile][row tile]
-#pragma unroll
-            for (int at = 0; at < 2; ++at)
-#pragma unroll
-                for (int bt = 0; bt < 2; ++bt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) c[at][bt][r] = cp[(size_t)(16 * bt) + ld * (size_t)(16 * at + 4 * r)];
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                const int kc = (a - 2 + qq) * BNR_NB;
-                const double *colrows = E + (size_t)(j * BNR_NB) + ld * (size_t)kc, *rowrows = E + (size_t)(rho * BNR_NB) + ld * (size_t)kc;
-                double av[2][8], bv[2][8];
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    const size_t o = (size_t)ln + ld * (size_t)(4 * ks + lq);
-                    av[0][ks] = colrows[o]; av[1][ks] = colrows[o + 16];
-                    bv[0][ks] = rowrows[o]; bv[1][ks] = rowrows[o + 16];
-                }
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-                    for (int at = 0; at < 2; ++at)
-#pragma unroll
-                        for (int bt = 0; bt < 2; ++bt) c[at][bt] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[at][ks], bv[bt][ks], c[at][bt], 0, 0, 0);
-            }
-#pragma unroll
-            for (int at = 0; at < 2; ++at)
-#pragma unroll
-                for (int bt = 0; bt < 2; ++bt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) cp[(size_t)(16 * bt) + ld * (size_t)(16 * at + 4 * r)] = c[at][bt][r];
+            if (nq == 4) bnr_super_update<4>(E, ld, rho, j, q0, ln, lq);
+            else bnr_super_update<2>(E, ld, rho, j, q0, ln, lq);
         }
         return;
     }

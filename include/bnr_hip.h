@@ -229,7 +229,9 @@ int bnr_chain_debug_copy(bnr_chain *chain, int32_t which, double *out, int64_t c
  *   "gram_variant" 0 (default): the Gram kernel is chosen per launch (k_gram8 when the launch has more than two workgroups per CU,
  *               k_gram otherwise); 8 / 16 force one of them.  Both write the same partial tiles bit for bit.
  *   "profiling" 1: record HIP events around every k_gram launch (forces eager launches), see bnr_chain_last_timing
- *   "factor_variant" 0 / -1 (default): right-looking factorization (k_gram_reduce + k_chol_step); 1: left-looking (k_chol_ll)
+ *   "factor_variant" -1 (default): chosen by size -- 0 below n_pad = 1024, 3 from there on; 0: right-looking factorization, one
+ *               32-column panel per launch (k_gram_reduce + k_chol_step); 1: left-looking (k_chol_ll); 2: right-looking, two panels per
+ *               launch (k_chol_step2); 3: 2 with the whole trailing matrix updated at every other launch only (K = 128)
  *   "pipeline"  1 (needs factor_variant 1): factorization beside the Gram (persistent Gram off the reserved CUs, gates per tile column)
  *   "gate_us"   how long a gate of the pipelined schedule polls before it gives up (default 3000)
  *   "byte_x"    (chains only) 0: the X passes read the f64 matrix although a byte image of X exists; 1 (default): the byte image
