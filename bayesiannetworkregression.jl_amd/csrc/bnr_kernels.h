@@ -979,6 +979,9 @@ __device__ __forceinline__ bnr_d4 bnr_tile_update(const double *colrows, const d
 // later with LDS broadcast reads of the published column (sCol, double buffered), so that the LDS latency hides behind the
 // next pivot's rsqrt chain.  (Measured on gfx950: a ds_write is NOT ordered before later ds_reads of the same wave
 // without an s_waitcnt.)
+#ifndef BNR_SWEEP_RL
+#define BNR_SWEEP_RL 1
+#endif
 template <int COFF>
 __device__ __forceinline__ int bnr_sweep16(double (&a)[16], int lane, double (*sCol)[BNR_NB])
 {
@@ -1000,11 +1003,20 @@ __device__ __forceinline__ int bnr_sweep16(double (&a)[16], int lane, double (*s
         // the reciprocal square root is started BEFORE the wait for the previous column's LDS write: the wave issues in
         // order, so the v_rsq_f64 (quarter rate, long latency) runs while the LDS round trip completes
         double y = __builtin_amdgcn_rsq(piv);
+#if BNR_SWEEP_RL
+        // the multipliers l_{k,j-1} of the lagged update come from the previous column's register by v_readlane (wave-uniform scalars):
+        // no LDS write -> wait -> read round trip per pivot
+        if (j >= 1) {
+#pragma unroll
+            for (int k = j + 2; k < 16; ++k) tk[k] = bnr_readlane(lprev, COFF + k);
+        }
+#else
         if (j >= 1) {
             asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(y) : "memory");
 #pragma unroll
             for (int k = j + 2; k < 16; ++k) tk[k] = sCol[(j - 1) & 1][COFF + k];
         }
+#endif
         // v_rsq_f64 is good to 2^-24 (tools/rsq_precision.hip); ONE third-order step y (1 + e/2 + 3 e^2/8), e = 1 - x y^2,
         // gives 1.2 ulp -- what two Newton steps give -- in 5 instead of 8 operations and depth 4 instead of 6
         const double e = fma(-(piv * y), y, 1.0);
@@ -1015,14 +1027,18 @@ __device__ __forceinline__ int bnr_sweep16(double (&a)[16], int lane, double (*s
         a[j] = lj;
         if (j + 1 < 16) a[j + 1] = fma(-lj, t1, a[j + 1]);
         if (j + 2 < 16) a[j + 2] = fma(-lj, s3 * rinv, a[j + 2]);
+#if !BNR_SWEEP_RL
         if (lane < 32) sCol[j & 1][lane] = lj;
+#endif
         if (j >= 1) {
 #pragma unroll
             for (int k = j + 2; k < 16; ++k) a[k] = fma(-lprev, tk[k], a[k]);
         }
         lprev = lj;
     }
+#if !BNR_SWEEP_RL
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     return bad;
 }
 
