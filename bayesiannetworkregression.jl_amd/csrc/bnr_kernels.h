@@ -1055,8 +1055,14 @@ struct bnr_panel_lds {
 // Two halves of 16 columns (lane = row: lanes 0..31 rows of the diagonal block, lanes 32..63 rows of the own block);
 // between them the second half is updated with the first by f64 MFMA on all four waves:
 //   A[:, 16:32] -= L[:, 0:16] L[16:32, 0:16]'
-__device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &cD, const bnr_d4 &cB, int tid)
+__device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &cD, const bnr_d4 &cB, int tid, double *dst, size_t ld, unsigned long long *ph = nullptr)
 {
+#ifdef BNR_STAMPS
+#define BNR_PH(i) do { if (ph && tid == 0) ph[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BNR_PH(i) do { } while (0)
+#endif
+    BNR_PH(0);
     const int wave = tid >> 6, lane = tid & 63, mt = wave >> 1, nt = wave & 1, ln = lane & 15, lq = lane >> 4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1064,6 +1070,7 @@ __device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &
         sh.sB[(nt * 16 + ln) + BNR_LP * (mt * 16 + lq + 4 * r)] = cB[r];
     }
     __syncthreads();
+    BNR_PH(1);
     const int rr = lane & 31;
     double a1[16], a2[16];
     int bad = 0;
@@ -1071,11 +1078,14 @@ __device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &
         const double *src = (lane < 32) ? sh.sD : sh.sB;
 #pragma unroll
         for (int c = 0; c < 16; ++c) a1[c] = src[rr + BNR_LP * c];
+        BNR_PH(2);
         bad = bnr_sweep16<0>(a1, lane, sh.sCol);
+        BNR_PH(3);
 #pragma unroll
         for (int c = 0; c < 16; ++c) sh.sL1[c * BNR_L1S + lane] = a1[c];
     }
     __syncthreads();
+    BNR_PH(4);
     {
         // wave w owns rows 16 w .. 16 w + 15 of the 64-row panel
         double *sx = (wave < 2) ? sh.sD : sh.sB;
@@ -1093,18 +1103,22 @@ __device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &
         for (int r = 0; r < 4; ++r) sx[(rowb + ln) + BNR_LP * (16 + lq + 4 * r)] = c[r];
     }
     __syncthreads();
+    BNR_PH(5);
     if (wave == 0) {
         const double *src = (lane < 32) ? sh.sD : sh.sB;
 #pragma unroll
         for (int c = 0; c < 16; ++c) a2[c] = src[rr + BNR_LP * (16 + c)];
+        BNR_PH(6);
         bad |= bnr_sweep16<16>(a2, lane, sh.sCol);
-        // hand the swept own block back through LDS (the factored diagonal block is not needed by anybody later)
-        if (lane >= 32) {
+        BNR_PH(7);
+        // the swept own block goes to E straight from the sweeping wave's registers (lane = row: 32 coalesced 256-byte stores; the
+        // LDS hand-back + barrier + store by all four waves cost ~1000 cycles at the end of every panel step); the factored
+        // diagonal block is not needed by anybody later
+        if (dst && lane >= 32) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) { sh.sB[rr + BNR_LP * c] = a1[c]; sh.sB[rr + BNR_LP * (16 + c)] = a2[c]; }
+            for (int c = 0; c < 16; ++c) { dst[(size_t)rr + ld * (size_t)c] = a1[c]; dst[(size_t)rr + ld * (size_t)(16 + c)] = a2[c]; }
         }
     }
-    __syncthreads();
     return bad;
 }
 template <class SRC>
@@ -1247,19 +1261,16 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
         }
     }
     BNR_STAMP(2);
-    const int bad = bnr_panel_sweep(sh, cD, cB, tid);
+    // (the factored diagonal block L_pp is needed by nobody after this launch and is NOT written back: every panel workgroup of
+    // this launch reads the unfactored block (p,p) whenever it happens to start)
+    double *dst = rho != p ? E + (size_t)(rho * BNR_NB) + ld * (size_t)pc : nullptr;
+#ifdef BNR_STAMPS
+    const int bad = bnr_panel_sweep(sh, cD, cB, tid, dst, ld, b == 0 ? cd.dbg + 128 + p * 8 : nullptr);
+#else
+    const int bad = bnr_panel_sweep(sh, cD, cB, tid, dst, ld);
+#endif
     if (bad && tid == 0 && b == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[7], 1ull); }
     BNR_STAMP(3);
-    // The factored diagonal block L_pp is needed by nobody after this launch and is NOT written back: every panel
-    // workgroup of this launch reads the unfactored block (p,p) whenever it happens to start.
-    if (rho != p) {
-        const int r = tid & 31, c0 = tid >> 5;
-#pragma unroll
-        for (int mm = 0; mm < 4; ++mm) {
-            int c = c0 + 8 * mm;
-            E[(size_t)(rho * BNR_NB + r) + ld * (size_t)(pc + c)] = sh.sB[r + BNR_LP * c];
-        }
-    }
     BNR_STAMP(4);
 #ifdef BNR_STAMPS
     if (tid == 0) atomicMax((unsigned long long *)&cd.dbg[p * 8 + 5], (unsigned long long)__builtin_amdgcn_s_memrealtime());
