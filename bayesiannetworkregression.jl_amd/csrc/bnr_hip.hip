@@ -53,6 +53,7 @@ struct bnr_exec {
     size_t fj_next = 0;
     int overlap = 1;
     int gram_variant = 0;                               // 0: chosen per launch; 8 / 16: k_gram8 / k_gram forced (tests, experiments)
+    int fuse_reduce = -1;                               // -1 / 1: launch 0 of the one-panel factorization also sums the Gram's K-split partials (no k_gram_reduce launch); 0: separate pass
     int spw_cap = 4;                                    // super blocks per update workgroup of the factorization, at most
     int factor_variant = -1;                            // -1: chosen by size; 0: right-looking k_chol_step (+ k_gram_reduce); 1: left-looking k_chol_ll
     int use_graph = 1, graph_k = 8;
@@ -651,6 +652,12 @@ static bool pipelined(const bnr_exec &x)
 // two panels per launch with the K = 128 trailing update (variant 3) where the trailing update is bandwidth-bound: n_pad >= 1024
 // (n = 2000 one chain 424 -> 448 it/s, n = 1000 eight chains 5.49 -> 5.88 k it/s; at n = 500 it is a draw and the one-panel launches stay)
 static bool two_panel_default(const bnr_exec &x) { return x.shape->n_pad >= 1024; }
+// the one-panel right-looking factorization (k_chol_step) is the one that runs, and its first launch takes over k_gram_reduce's work
+static bool reduce_in_chol(const bnr_exec &x)
+{
+    const bool one_panel = x.factor_variant == 0 || (x.factor_variant < 0 && !two_panel_default(x));
+    return one_panel && x.fuse_reduce != 0;
+}
 static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
 {
     const bnr_dev &d = *x.shape;
@@ -697,7 +704,7 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
         }
     }
     if (timed) HIPNOTE(hipEventRecord(e1, st));
-    if (!left_looking(x)) BNR_LAUNCH(k_gram_reduce, dim3(ntl, 8, x.nb), dim3(256), 0, st, x, s);
+    if (!left_looking(x) && !reduce_in_chol(x)) BNR_LAUNCH(k_gram_reduce, dim3(ntl, 8, x.nb), dim3(256), 0, st, x, s);
 }
 static void launch_rhs(bnr_exec &x, int s) { BNR_LAUNCH(k_rhs, dim3(x.shape->n_pad / 64, 1, x.nb), dim3(256), 0, x.stream, x, s); }
 static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
@@ -722,9 +729,15 @@ static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
     }
     // update workgroups: one 32 x 32 block each while panels + updates of all members fit the chip in one round (two 256-thread
     // workgroups per CU); otherwise (large n, groups) 64 x 64 super blocks
-    const int ncu = x.ncu;
+    const int ncu = x.ncu, fuse0 = reduce_in_chol(x) ? 1 : 0;
     for (int p = 0; p < nbk; ++p) {
         const int npan = bnr_chol_npanel(nbk, p), ntile = bnr_chol_ntile(nbk, p);
+        if (p == 0 && fuse0) {
+            // launch 0: the first panel (its workgroups sum the partial tiles of column block 0 themselves) beside the reduction of all the other tiles
+            const int ntl = x.shape->ntile * (x.shape->ntile + 1) / 2;
+            BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + 8 * ntl), dim3(256), 0, st, x, p, s, 1, 1, 1);
+            continue;
+        }
         const int room = std::max(64, 2 * ncu - x.nb * npan);
         if (x.nb * ntile > room) {                       // many blocks: 64 x 64 super blocks, one 32 x 32 block per wave
             const int nsup = bnr_chol_nsuper(nbk, p);
@@ -733,9 +746,9 @@ static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
             // bandwidth-bound and wants every workgroup in flight at once: n=2000 408 vs 421 it/s)
             const int freecu = ncu - x.nb * npan;
             const int spw = (freecu > 0 && nbk <= 24) ? std::min(x.spw_cap, std::max(1, (x.nb * nsup + freecu - 1) / freecu)) : 1;
-            BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + (nsup + spw - 1) / spw), dim3(256), 0, st, x, p, s, 0, spw);
+            BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + (nsup + spw - 1) / spw), dim3(256), 0, st, x, p, s, 0, spw, fuse0);
         } else {
-            BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + ntile), dim3(256), 0, st, x, p, s, 1, 1);
+            BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + ntile), dim3(256), 0, st, x, p, s, 1, 1, fuse0);
         }
     }
 }
@@ -1137,6 +1150,10 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
     if (!strcmp(name, "gram_variant")) {
         if (value != 0 && value != 8 && value != 9 && value != 16) return fail(BNR_ERR_BAD_ARG, "gram_variant must be 0 (auto), 8, 9 (persistent) or 16");
         x.gram_variant = (int)value; drop_graph(x); return BNR_OK;
+    }
+    if (!strcmp(name, "fuse_reduce")) {
+        if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "fuse_reduce must be -1 (default: on), 0 or 1");
+        x.fuse_reduce = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "spw_cap")) {
         if (value < 1 || value > 4) return fail(BNR_ERR_BAD_ARG, "spw_cap must be 1..4");

@@ -1121,8 +1121,101 @@ __device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &
     }
     return bad;
 }
+// First touch of G + I: the 32 x 32 block (rho, c), rho >= c, as MFMA accumulator fragments -- NT x NT tiles of 16 x 16 starting at
+// tile (at0, bt0) (columns at, rows bt; lane: row 16 bt + ln, columns 16 at + lq + 4 r) -- with the K-slice partials summed per
+// element in k_gram_reduce's order (ks ascending from 0.0, then + 1 on the diagonal).  The loop runs over the K slices with
+// all elements of a lane in flight per slice (the partial tiles come from HBM: one element at a time would cost ksplit x 16
+// dependent round trips).
+// fresh: the partial tiles were written while this kernel was already running (factorization beside the Gram), possibly through
+// another XCD's L2: read them past the own L2 (sc1 loads) -- an acquire fence instead would invalidate the whole L2 of this XCD,
+// once per wave, under everybody who works from it (measured: +30 us on every gated launch).
+__device__ __forceinline__ double bnr_ld_fresh(const double *p, bool fresh)
+{
+    return fresh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <int NT>
+__device__ __forceinline__ void bnr_gsum_frag(const bnr_dev &cd, int rho, int c, int at0, int bt0, int ln, int lq, bnr_d4 (&out)[NT][NT], bool fresh)
+{
+    const int ti = rho >> 1, tj = c >> 1, ntl = cd.ntile * (cd.ntile + 1) / 2;
+    const size_t tsz = BNR_GT * BNR_GT, plane = (size_t)ntl * tsz;
+    const double *src = cd.Gpart + (size_t)(ti * (ti + 1) / 2 + tj) * tsz + (size_t)((c & 1) * BNR_NB + 16 * at0 + lq) * BNR_GT + (rho & 1) * BNR_NB + 16 * bt0 + ln;
+#pragma unroll
+    for (int at = 0; at < NT; ++at)
+#pragma unroll
+        for (int bt = 0; bt < NT; ++bt) out[at][bt] = bnr_d4{0.0, 0.0, 0.0, 0.0};
+    // KU slices per round, all in flight; a slice past the last one is read again from the last plane and enters as + 0.0, which
+    // changes nothing (the running sum is never -0.0)
+    constexpr int KU = NT == 1 ? 8 : 4;
+    const int klast = cd.ksplit - 1;
+    for (int ks0 = 0; ks0 < cd.ksplit; ks0 += KU) {
+        bnr_d4 v[KU][NT][NT];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const size_t po = (size_t)(ks0 + u < klast ? ks0 + u : klast) * plane;
+#pragma unroll
+            for (int at = 0; at < NT; ++at)
+#pragma unroll
+                for (int bt = 0; bt < NT; ++bt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[u][at][bt][r] = bnr_ld_fresh(src + po + (size_t)(16 * at + 4 * r) * BNR_GT + 16 * bt, fresh);
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const double keep = (ks0 + u <= klast) ? 1.0 : 0.0;
+#pragma unroll
+            for (int at = 0; at < NT; ++at)
+#pragma unroll
+                for (int bt = 0; bt < NT; ++bt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) out[at][bt][r] += (ks0 + u <= klast) ? v[u][at][bt][r] : 0.0;
+            (void)keep;
+        }
+    }
+    if (rho == c) {
+#pragma unroll
+        for (int at = 0; at < NT; ++at)
+#pragma unroll
+            for (int bt = 0; bt < NT; ++bt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (16 * (bt0 + bt) + ln == 16 * (at0 + at) + lq + 4 * r) out[at][bt][r] += 1.0;
+    }
+}
+// One k_gram_reduce workgroup's work (tile t, eighth `part`) done by a workgroup of launch 0 of the factorization (fuse0): the same sums
+// in the same order, the same Y = I share and stamp -- except what launch 0's own panel workgroups produce at the same time: the
+// first 32 columns of E's matrix part (they read the partial tiles themselves and write the swept blocks) and the block Y[0:32, 0:32].
+__device__ __forceinline__ void bnr_reduce_part(const bnr_dev &cd, int t, int part, int nwg, int wg, int s)
+{
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int ntl = cd.ntile * (cd.ntile + 1) / 2;
+    const size_t ld = (size_t)2 * cd.n_pad + BNR_NB, tsz = BNR_GT * BNR_GT;
+    const int idx = part * 512 + 2 * threadIdx.x;
+    const double *src = cd.Gpart + (size_t)t * tsz + idx;
+    bnr_d2 acc = {0.0, 0.0};
+    int ks = 0;
+    for (; ks + 3 < cd.ksplit; ks += 4) {
+        bnr_d2 v0 = *(const bnr_d2 *)(src + (size_t)ks * ntl * tsz), v1 = *(const bnr_d2 *)(src + (size_t)(ks + 1) * ntl * tsz);
+        bnr_d2 v2 = *(const bnr_d2 *)(src + (size_t)(ks + 2) * ntl * tsz), v3 = *(const bnr_d2 *)(src + (size_t)(ks + 3) * ntl * tsz);
+        acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; ks < cd.ksplit; ++ks) acc += *(const bnr_d2 *)(src + (size_t)ks * ntl * tsz);
+    const int i = ti * BNR_GT + idx % BNR_GT, j = tj * BNR_GT + idx / BNR_GT;
+    if (i == j) acc[0] += 1.0;
+    if (i + 1 == j) acc[1] += 1.0;
+    if (j >= BNR_NB) *(bnr_d2 *)(cd.E + (size_t)i + ld * j) = acc;
+    const int np = cd.n_pad;
+    for (size_t e = ((size_t)wg * 256 + threadIdx.x) * 2; e < (size_t)np * np; e += (size_t)nwg * 512) {
+        const int r = (int)(e % np), c = (int)(e / np);
+        if (r < BNR_NB && c < BNR_NB) continue;
+        bnr_d2 v = {(r == c) ? 1.0 : 0.0, (r + 1 == c) ? 1.0 : 0.0};
+        *(bnr_d2 *)(cd.E + (size_t)(np + r) + ld * c) = v;
+    }
+    if (threadIdx.x == 0) cd.stamp[t * 8 + part] = cd.plan[cd.pbase[0] + s].it;
+    if (wg == 0 && (int)threadIdx.x <= cd.ntile) cd.gprog[threadIdx.x] = 0u;
+}
 template <class SRC>
-__global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p, int s, int tpw, int spw)
+__global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p, int s, int tpw, int spw, int fuse0)
 {
     const bnr_dev &cd = chain_src.get_x();               // grid = (chains, workgroups): blockIdx.x = chain, blockIdx.y = workgroup
     __shared__ bnr_panel_lds sh;
@@ -1133,6 +1226,12 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
     const int mt = wave >> 1, nt = wave & 1;               // this wave's 16x16 tile of a 32x32 block: columns mt, rows nt
     const int ln = lane & 15, lq = lane >> 4;
     double *E = cd.E;
+    if (p == 0 && (int)blockIdx.y >= npanel) {
+        // ------------------------------------------------ launch 0 with fuse0: the reduction of the Gram's K-split partial tiles, beside the first panel
+        const int wg = (int)blockIdx.y - npanel;
+        bnr_reduce_part(cd, wg >> 3, wg & 7, (int)gridDim.y - npanel, wg, s);
+        return;
+    }
     if ((int)blockIdx.y >= npanel) {
         // ------------------------------------------------ role B: E[rho,j] -= L[rho,p-1] L[j,p-1]'
         const int m = nbk - (p + 1);
@@ -1225,8 +1324,8 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
     }
     // ---------------------------------------------------- role A: panel workgroup
     const int b = blockIdx.y;
-    if (p == 0 && b == 0) {
-        // cheap safety net for the two-branch schedule: every k_gram_reduce workgroup of THIS sweep must have finished
+    if (p == (fuse0 ? 1 : 0) && b == 0) {
+        // cheap safety net for the two-branch schedule: every reduction workgroup of THIS sweep (k_gram_reduce, or launch 0's with fuse0) must have finished
         const unsigned int it = cd.plan[cd.pbase[0] + s].it;
         const int nred = 8 * (cd.ntile * (cd.ntile + 1) / 2);
         for (int w = tid; w < nred; w += blockDim.x)
@@ -1249,7 +1348,17 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
     if (b < nbk - p) rho = p + b;                          // matrix rows p..nbk-1
     else rho = nbk + (b - (nbk - p));                      // identity block rows 0..p
     bnr_d4 cD, cB;
-    {
+    if (p == 0 && fuse0) {
+        // first touch of column block 0: the K-slice partials summed here (k_gram_reduce's order), the identity block row generated
+        bnr_d4 t1[1][1];
+        bnr_gsum_frag<1>(cd, 0, 0, mt, nt, ln, lq, t1, false);
+        cD = t1[0][0];
+        if (rho < nbk) { bnr_gsum_frag<1>(cd, rho, 0, mt, nt, ln, lq, t1, false); cB = t1[0][0]; }
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cB[r] = (nt * 16 + ln == mt * 16 + lq + 4 * r) ? 1.0 : 0.0;
+        }
+    } else {
         const double *dp = E + (size_t)(pc + nt * 16 + ln) + ld * (size_t)(pc + mt * 16 + lq);
         const double *bp = E + (size_t)(rho * BNR_NB + nt * 16 + ln) + ld * (size_t)(pc + mt * 16 + lq);
 #pragma unroll
@@ -1564,65 +1673,6 @@ __global__ __launch_bounds__(256, 1) void k_chol_step2(const SRC chain_src, int 
 #define BNR_LL_WAVE (BNR_NB * BNR_LP + 16 * BNR_L1W + 2 * BNR_NB)            // doubles per wave: sB | sL1 | sCol
 #define BNR_LL_LDS ((BNR_NB * BNR_LP + 16 * BNR_L1W + 4 * BNR_LL_WAVE) * sizeof(double))   // + shared sD | sL1D
 
-// First touch of G + I: the 32 x 32 block (rho, c), rho >= c, as MFMA accumulator fragments -- NT x NT tiles of 16 x 16 starting at
-// tile (at0, bt0) (columns at, rows bt; lane: row 16 bt + ln, columns 16 at + lq + 4 r) -- with the K-slice partials summed per
-// element in k_gram_reduce's order (ks ascending from 0.0, then + 1 on the diagonal).  The loop runs over the K slices with
-// all elements of a lane in flight per slice (the partial tiles come from HBM: one element at a time would cost ksplit x 16
-// dependent round trips).
-// fresh: the partial tiles were written while this kernel was already running (factorization beside the Gram), possibly through
-// another XCD's L2: read them past the own L2 (sc1 loads) -- an acquire fence instead would invalidate the whole L2 of this XCD,
-// once per wave, under everybody who works from it (measured: +30 us on every gated launch).
-__device__ __forceinline__ double bnr_ld_fresh(const double *p, bool fresh)
-{
-    return fresh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-template <int NT>
-__device__ __forceinline__ void bnr_gsum_frag(const bnr_dev &cd, int rho, int c, int at0, int bt0, int ln, int lq, bnr_d4 (&out)[NT][NT], bool fresh)
-{
-    const int ti = rho >> 1, tj = c >> 1, ntl = cd.ntile * (cd.ntile + 1) / 2;
-    const size_t tsz = BNR_GT * BNR_GT, plane = (size_t)ntl * tsz;
-    const double *src = cd.Gpart + (size_t)(ti * (ti + 1) / 2 + tj) * tsz + (size_t)((c & 1) * BNR_NB + 16 * at0 + lq) * BNR_GT + (rho & 1) * BNR_NB + 16 * bt0 + ln;
-#pragma unroll
-    for (int at = 0; at < NT; ++at)
-#pragma unroll
-        for (int bt = 0; bt < NT; ++bt) out[at][bt] = bnr_d4{0.0, 0.0, 0.0, 0.0};
-    // KU slices per round, all in flight; a slice past the last one is read again from the last plane and enters as + 0.0, which
-    // changes nothing (the running sum is never -0.0)
-    constexpr int KU = NT == 1 ? 8 : 4;
-    const int klast = cd.ksplit - 1;
-    for (int ks0 = 0; ks0 < cd.ksplit; ks0 += KU) {
-        bnr_d4 v[KU][NT][NT];
-#pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            const size_t po = (size_t)(ks0 + u < klast ? ks0 + u : klast) * plane;
-#pragma unroll
-            for (int at = 0; at < NT; ++at)
-#pragma unroll
-                for (int bt = 0; bt < NT; ++bt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[u][at][bt][r] = bnr_ld_fresh(src + po + (size_t)(16 * at + 4 * r) * BNR_GT + 16 * bt, fresh);
-        }
-#pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            const double keep = (ks0 + u <= klast) ? 1.0 : 0.0;
-#pragma unroll
-            for (int at = 0; at < NT; ++at)
-#pragma unroll
-                for (int bt = 0; bt < NT; ++bt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) out[at][bt][r] += (ks0 + u <= klast) ? v[u][at][bt][r] : 0.0;
-            (void)keep;
-        }
-    }
-    if (rho == c) {
-#pragma unroll
-        for (int at = 0; at < NT; ++at)
-#pragma unroll
-            for (int bt = 0; bt < NT; ++bt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (16 * (bt0 + bt) + ln == 16 * (at0 + at) + lq + 4 * r) out[at][bt][r] += 1.0;
-    }
-}
 // Before the first read of tile column tc of Gpart: all its (tile, K slice) tasks of THIS sweep's Gram must have been published.
 // spin_us = 0: the Gram launch is complete (single-stream schedule, hooks) -- a shortfall is a stream-ordering violation.
 // spin_us > 0: the Gram may still be running beside this launch; lane 0 polls (relaxed, with s_sleep) for at most spin_us, then
