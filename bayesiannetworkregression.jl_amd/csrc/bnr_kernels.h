@@ -888,9 +888,16 @@ __global__ void k_cu_census(unsigned *out, int spin)
 // k_gram_reduce: G = sum_ks partial + I into the lower tiles of E, and Y = I.  grid = (lower tiles, 4), 256 threads.
 __host__ __device__ inline int bnr_ldE(int n_pad) { return 2 * n_pad + BNR_NB; }
 
+// Kernels of the sweep's critical chain (reduction, panel steps, solve, back-projection) raise the issue priority of every wave with their
+// first instruction: the scalar branch of the sweep runs beside them on another queue, and a young wave that lands on a SIMD where older
+// waves of k_tail / k_node keep the VALU busy is otherwise served last (tools/interfere_probe.hip: a chain of 16 dependent 5 us launches
+// takes 8.3 instead of 6.6 us per link beside eight 1024-thread VALU-bound workgroups, 13.9 instead of 7.7 with 1096 workgroups per link;
+// with s_setprio 3 it is 6.6 / 7.9 again, and beside a streaming kernel 13 instead of 21 us).
+#define BNR_CRITICAL_PATH() __builtin_amdgcn_s_setprio(3)
 template <class SRC>
 __global__ __launch_bounds__(256) void k_gram_reduce(const SRC chain_src, int s)
 {
+    BNR_CRITICAL_PATH();
     const bnr_dev &cd = chain_src.get();
     // grid = (lower tiles, 8): each workgroup sums 512 elements (one 16-byte pair per thread) of one tile over the K slices
     int t = blockIdx.x, ti = 0;
@@ -1217,6 +1224,7 @@ __device__ __forceinline__ void bnr_reduce_part(const bnr_dev &cd, int t, int pa
 template <class SRC>
 __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p, int s, int tpw, int spw, int fuse0)
 {
+    BNR_CRITICAL_PATH();
     const bnr_dev &cd = chain_src.get_x();               // grid = (chains, workgroups): blockIdx.x = chain, blockIdx.y = workgroup
     __shared__ bnr_panel_lds sh;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nbk = cd.n_pad / BNR_NB;
@@ -1495,6 +1503,7 @@ __device__ __forceinline__ void bnr_super_update(double *E, size_t ld, int rho, 
 template <class SRC>
 __global__ __launch_bounds__(256, 1) void k_chol_step2(const SRC chain_src, int P, int s, int spw, int lazy)
 {
+    BNR_CRITICAL_PATH();
     const bnr_dev &cd = chain_src.get_x();               // grid = (chains, workgroups)
     __shared__ bnr_panel2_lds sh;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nbk = cd.n_pad / BNR_NB;
@@ -1975,6 +1984,7 @@ __global__ __launch_bounds__(256) void k_rhs(const SRC chain_src, int s)
 template <class SRC>
 __global__ __launch_bounds__(256) void k_solve_w(const SRC chain_src)
 {
+    BNR_CRITICAL_PATH();
     const bnr_dev &cd = chain_src.get();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, np = cd.n_pad;
     const int c = blockIdx.x * 4 + wave;
@@ -1991,6 +2001,7 @@ __global__ __launch_bounds__(256) void k_solve_w(const SRC chain_src)
 template <class SRC>
 __global__ __launch_bounds__(1024) void k_solve_a4(const SRC chain_src)
 {
+    BNR_CRITICAL_PATH();
     const bnr_dev &cd = chain_src.get();
     extern __shared__ double shs[];                         // n_pad (w) + 32*33 partials
     double *swv = shs, *spart = shs + cd.n_pad;
@@ -2028,6 +2039,7 @@ __global__ __launch_bounds__(1024) void k_solve_a4(const SRC chain_src)
 template <class SRC>
 __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, int flags, int nchains, int nslot)
 {
+    BNR_CRITICAL_PATH();
     // 1-D grid = round_up(blocks, 8) x chains, decoded like k_gram: the workgroups of the group's chains that read the same
     // 32 columns of X are neighbours on the same XCD and share them through its L2
     const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
