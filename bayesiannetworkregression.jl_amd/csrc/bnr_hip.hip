@@ -54,6 +54,7 @@ struct bnr_exec {
     int overlap = 1;
     int gram_variant = 0;                               // 0: chosen per launch; 8 / 16: k_gram8 / k_gram forced (tests, experiments)
     int fuse_reduce = -1;                               // -1 / 1: launch 0 of the one-panel factorization also sums the Gram's K-split partials (no k_gram_reduce launch); 0: separate pass
+    int group_xpass = -1;                               // -1 / 1: a group whose members share X runs the X pass with one workgroup per chunk for all chains; 0: per chain
     int spw_cap = 4;                                    // super blocks per update workgroup of the factorization, at most
     int factor_variant = -1;                            // -1: chosen by size; 0: right-looking k_chol_step (+ k_gram_reduce); 1: left-looking k_chol_ll
     int use_graph = 1, graph_k = 8;
@@ -633,8 +634,23 @@ static int check_launch(const char *what)
 
 static void launch_node(bnr_exec &x, int s, int mode)
 { BNR_LAUNCH(k_node, dim3(x.shape->V, 1, x.nb), dim3(64), 64 * (2 * x.shape->R + 1) * sizeof(double), x.stream, x, s, mode); }
+// the members of a lockstep group read the same device copy of X (chains of one fit made with bnr_chain_create_like)
+static bool group_shares_x(const bnr_exec &x)
+{
+    if (x.nb < 2 || !x.cds_pin) return false;
+    for (int i = 1; i < x.nb; ++i)
+        if (x.cds_pin[i].X != x.cds_pin[0].X || x.cds_pin[i].X8 != x.cds_pin[0].X8) return false;
+    return true;
+}
 static void launch_xpass(bnr_exec &x, int s, int which)
-{ BNR_LAUNCH(k_xpass, dim3(round_up(x.shape->nblk_x, 8) * x.nb), dim3(256), 3 * x.shape->chunk_x * sizeof(double), x.stream, x, s, which, x.nb); }
+{
+    if (which == 3 && x.group_xpass != 0 && group_shares_x(x) && 16 * (size_t)x.shape->chunk_x * sizeof(double) <= 48 * 1024) {
+        // one workgroup per column chunk and row slice for all members: X comes out of the L2s once, not once per chain
+        hipLaunchKernelGGL(k_xpass_group, dim3(x.shape->nblk_x * ((x.shape->n_pad + 255) / 256)), dim3(256), 16 * x.shape->chunk_x * sizeof(double), x.stream, bnr_many{x.cds}, s, x.nb);
+        return;
+    }
+    BNR_LAUNCH(k_xpass, dim3(round_up(x.shape->nblk_x, 8) * x.nb), dim3(256), 3 * x.shape->chunk_x * sizeof(double), x.stream, x, s, which, x.nb);
+}
 // Which factorization: right-looking (k_chol_step behind k_gram_reduce: the trailing update spread over the whole chip) unless the
 // caller asks for the left-looking one (k_chol_ll: no reduction pass, ceil(nbk/4) + nbk - 1 workgroups per chain and launch, can
 // run beside the Gram).  Same tables bit for bit.
@@ -1074,6 +1090,7 @@ int bnr_group_create(bnr_chain *const *chains, int32_t nchains, bnr_group **out)
     int rc = exec_init(g->x, chains[0]->device, nchains, &chains[0]->d);
     if (rc) { exec_free(g->x); delete g; return rc; }
     g->x.gq = chains[0]->x.gq;
+    for (size_t i = 0; i < g->m.size(); ++i) g->x.cds_pin[i] = g->m[i]->d;   // host copy from the start: launch choices made at capture time (group_shares_x) read it
     for (bnr_chain *c : g->m) c->group = g;
     *out = g;
     return BNR_OK;
@@ -1154,6 +1171,10 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
     if (!strcmp(name, "fuse_reduce")) {
         if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "fuse_reduce must be -1 (default: on), 0 or 1");
         x.fuse_reduce = (int)value; drop_graph(x); return BNR_OK;
+    }
+    if (!strcmp(name, "group_xpass")) {
+        if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "group_xpass must be -1 (default: on), 0 or 1");
+        x.group_xpass = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "spw_cap")) {
         if (value < 1 || value > 4) return fail(BNR_ERR_BAD_ARG, "spw_cap must be 1..4");

@@ -431,6 +431,66 @@ __global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int w
     }
 }
 
+// k_xpass for a lockstep group whose members share the model matrix (chains of one fit: bnr_chain_create_like): ONE workgroup handles a
+// column chunk and a slice of 256 rows for up to eight chains at once -- an element of X is loaded once and enters 16 fused multiply-adds
+// (two GEMV partials per chain) instead of being fetched again by every chain's own workgroup.  Per chain the same products in the same
+// order (columns of the chunk ascending), the same partial vectors PW / PA: bitwise k_xpass.  Eight chains read an eighth of the
+// bytes from the L2s, and the factorization's panel steps that run beside this kernel keep their memory latency (a dependent launch
+// beside a streaming kernel: 21 us instead of 6.6, tools/interfere_probe.hip).  which = 3 only (W and sqrt(S) z1).
+//   grid = nblk_x x ceil(n_pad / 256), 256 threads, dynamic LDS = 2 x 8 x chunk_x doubles.
+__global__ __launch_bounds__(256) void k_xpass_group(const bnr_many chain_src, int s, int nchains)
+{
+    const bnr_dev &c0 = chain_src.at(0);                  // the geometry and the shared X, index maps
+    const int rs = (c0.n_pad + 255) / 256, bid = blockIdx.x / rs, slice = blockIdx.x % rs, tid = threadIdx.x;
+    const int chunk = c0.chunk_x, e0 = bid * chunk, ne = min(chunk, c0.q - e0), R = c0.R;
+    const size_t ld = c0.n_pad;
+    extern __shared__ double sh[];
+    double *sW = sh, *sZ = sh + 8 * chunk;                 // [chain][column of the chunk]
+    __shared__ double *s_pw[8], *s_pa[8];
+    const int i = slice * 256 + tid;
+    const bool live = i < c0.n_pad;                        // n_pad is a multiple of 64: the last slice may be short
+    const int ic = live ? i : 0;
+    for (int cb = 0; cb < nchains; cb += 8) {
+        const int nc = min(8, nchains - cb);
+        __syncthreads();
+        for (int it = tid; it < nc * chunk; it += 256) {
+            const int c = it / chunk, t = it - c * chunk;
+            const bnr_dev &cd = chain_src.at(cb + c);
+            const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
+            const double *row = cd.trace + (size_t)P.row * cd.rowlen, *prev = cd.trace + (size_t)P.prev * cd.rowlen;
+            double w = 0.0, zz = 0.0;
+            if (t < ne) {
+                const int e = e0 + t;
+                w = edge_W(row + cd.o_u, prev + cd.o_lam, R, cd.el[e], cd.ek[e]);
+                zz = sqrt(prev[cd.o_S + e]) * bnr_normal(cd.seed, P.it, SITE_G_Z1, (uint32_t)e, 0);
+                if (slice == 0) { cd.Wbuf[e] = w; cd.sz[e] = zz; }
+            }
+            sW[c * chunk + t] = w; sZ[c * chunk + t] = zz;
+        }
+        if (tid < nc) { const bnr_dev &cd = chain_src.at(cb + tid); s_pw[tid] = cd.PW; s_pa[tid] = cd.PA; }
+        __syncthreads();
+        double aw[8], aa[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { aw[c] = 0.0; aa[c] = 0.0; }
+#define BNR_XG_BODY(XP)                                                                                   \
+        for (int t0 = 0; t0 < ne; t0 += 16) {                                                             \
+            double xv[16];                                                                                \
+            _Pragma("unroll") for (int u = 0; u < 16; ++u) xv[u] = (double)(XP)[(size_t)(t0 + u < ne ? t0 + u : ne - 1) * ld]; \
+            _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                              \
+                if (t0 + u < ne) {                                                                        \
+                    _Pragma("unroll") for (int c = 0; c < 8; ++c)                                         \
+                        if (c < nc) { aw[c] = fma(xv[u], sW[c * chunk + t0 + u], aw[c]); aa[c] = fma(xv[u], sZ[c * chunk + t0 + u], aa[c]); } \
+                }                                                                                         \
+            }                                                                                             \
+        }
+        if (c0.X8) { const unsigned char *xp = c0.X8 + (size_t)e0 * ld + ic; BNR_XG_BODY(xp) }
+        else { const double *xp = c0.X + (size_t)e0 * ld + ic; BNR_XG_BODY(xp) }
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < nc && live) { s_pw[c][(size_t)bid * ld + i] = aw[c]; s_pa[c][(size_t)bid * ld + i] = aa[c]; }
+    }
+}
+
 // ===================================================================================== k_gram
 // G = X diag(S_prev) X'  (the n x n matrix of gibbs.jl:434 without the identity; tau cancels: Xt tau2 D Xt' = X D X').
 // v_mfma_f64_16x16x4_f64, D = A*B + C with A[m][k] (lane l: m = l&15, k = l>>4), B[k][n] (k = l>>4, n = l&15),
