@@ -54,6 +54,7 @@ struct bnr_exec {
     int overlap = 1;
     int gram_variant = 0;                               // 0: chosen per launch; 8 / 16: k_gram8 / k_gram forced (tests, experiments)
     int fuse_reduce = -1;                               // -1 / 1: launch 0 of the one-panel factorization also sums the Gram's K-split partials (no k_gram_reduce launch); 0: separate pass
+    int group_backproj = 0;                             // 1: the same for the back-projection / GIG kernel (opt-in: bitwise equal, measured no faster -- the block is bound by the latency of the draws' arithmetic)
     int group_xpass = -1;                               // -1 / 1: a group whose members share X runs the X pass with one workgroup per chunk for all chains; 0: per chain
     int spw_cap = 4;                                    // super blocks per update workgroup of the factorization, at most
     int factor_variant = -1;                            // -1: chosen by size; 0: right-looking k_chol_step (+ k_gram_reduce); 1: left-looking k_chol_ll
@@ -133,7 +134,7 @@ static int ensure_lds_attributes(int device)
     const void *fns[] = {(const void *)&k_tail<bnr_one>, (const void *)&k_tail<bnr_many>, (const void *)&k_backproj<bnr_one>,
                          (const void *)&k_backproj<bnr_many>, (const void *)&k_solve_a4<bnr_one>, (const void *)&k_solve_a4<bnr_many>,
                          (const void *)&k_chol_ll<bnr_one>, (const void *)&k_chol_ll<bnr_many>,
-                         (const void *)&k_gram_gate<bnr_one>, (const void *)&k_gram_gate<bnr_many>};
+                         (const void *)&k_gram_gate<bnr_one>, (const void *)&k_gram_gate<bnr_many>, (const void *)&k_backproj_group, (const void *)&k_xpass_group};
     for (const void *f : fns) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     done[device] = 1;
     return BNR_OK;
@@ -776,6 +777,15 @@ static void launch_solve(bnr_exec &x)
 static void launch_backproj(bnr_exec &x, int s, int flags)
 {
     size_t lds = std::max<size_t>(x.shape->n_pad + 64, (size_t)(3 * x.shape->R + 1) * 33) * sizeof(double);
+    if (flags == 7 && x.group_backproj == 1 && group_shares_x(x)) {
+        // one workgroup per block of 32 edges for BNR_BPG_CT members: X read once per tile of members, four speculative attempts per draw
+        const int R = x.shape->R, SA = std::max(std::max(x.shape->n_pad, (3 * R + 1) * 33), 32 * 22);
+        const size_t glds = (size_t)BNR_BPG_CT * (SA + 33 * R + 32) * sizeof(double);
+        if (glds <= 120 * 1024) {
+            hipLaunchKernelGGL(k_backproj_group, dim3(x.shape->nblk_bp, (x.nb + BNR_BPG_CT - 1) / BNR_BPG_CT), dim3(64 * BNR_BPG_CT * BNR_BPG_WPC), glds, x.stream, bnr_many{x.cds}, s, x.nb);
+            return;
+        }
+    }
     const int nslot = (x.nb * x.shape->nblk_bp <= 2 * x.ncu) ? 8 : 2;    // speculative GIG attempts per edge and round
     BNR_LAUNCH(k_backproj, dim3(round_up(x.shape->nblk_bp, 8) * x.nb), dim3(256), lds, x.stream, x, s, flags, x.nb, nslot);
 }
@@ -1171,6 +1181,10 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
     if (!strcmp(name, "fuse_reduce")) {
         if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "fuse_reduce must be -1 (default: on), 0 or 1");
         x.fuse_reduce = (int)value; drop_graph(x); return BNR_OK;
+    }
+    if (!strcmp(name, "group_backproj")) {
+        if (value < 0 || value > 1) return fail(BNR_ERR_BAD_ARG, "group_backproj must be 0 (default) or 1");
+        x.group_backproj = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "group_xpass")) {
         if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "group_xpass must be -1 (default: on), 0 or 1");

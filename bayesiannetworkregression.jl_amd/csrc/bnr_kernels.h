@@ -2233,6 +2233,234 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
     if (cap && lane < 32) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
 }
 
+// k_backproj for a lockstep group whose members share the model matrix: ONE workgroup of 64 CT WPC threads owns a block of 32 edges for CT
+// chains (CT = 8, WPC = 1: 512 threads; the chain's pointers and scalars in scalar registers so that the draws fit their vector registers).  A column of X is loaded once for the CT back-projections x_e' a4_c, and the GIG draws of all 32 CT (chain, edge)
+// pairs run side by side, 2 WPC speculative attempts each (a wave = one chain's 32 edges x 2 attempts: as many as the per-chain kernel makes
+// for a group -- attempts that are thrown away cost what they save once the chip is busy) -- the per-chain kernel's
+// workgroups are latency chains of 16-18 us (dot products 6, draws 7-10, sums 2.4 us: tools/stamps_bp.py), and eight chains' worth of
+// them took two rounds on the chip (31 us against 19 for one chain).  Per chain exactly the per-chain kernel's arithmetic: products
+// accumulated over the rows lane, lane + 64, ... then the wave reduction; the first accepted attempt of the counter sequence; the
+// partial sums per 32-edge block in the same order.  flags = 7 only.
+//   grid = (nblk_bp, ceil(chains / CT)); dynamic LDS = CT x (max(n_pad, (3R+1) 33) + 33 R + 32) doubles.
+// a GIG context through LDS (22 doubles)
+__device__ __forceinline__ void bnr_gig_ctx_put(const bnr_gig_ctx &g, double *d)
+{
+    d[0] = g.kind; d[1] = g.lambda_old; d[2] = g.lambda; d[3] = g.alpha; d[4] = g.omega; d[5] = g.xm; d[6] = g.t; d[7] = g.s; d[8] = g.nc; d[9] = g.ulo; d[10] = g.uhi;
+    d[11] = g.xoff; d[12] = g.x0; d[13] = g.k0; d[14] = g.A0; d[15] = g.A1; d[16] = g.A2; d[17] = g.k1; d[18] = g.k2; d[19] = g.Atot; d[20] = g.x0l; d[21] = g.half;
+}
+__device__ __forceinline__ void bnr_gig_ctx_get(bnr_gig_ctx &g, const double *d)
+{
+    g.kind = (int)d[0]; g.lambda_old = d[1]; g.lambda = d[2]; g.alpha = d[3]; g.omega = d[4]; g.xm = d[5]; g.t = d[6]; g.s = d[7]; g.nc = d[8]; g.ulo = d[9]; g.uhi = d[10];
+    g.xoff = d[11]; g.x0 = d[12]; g.k0 = d[13]; g.A0 = d[14]; g.A1 = d[15]; g.A2 = d[16]; g.k1 = d[17]; g.k2 = d[18]; g.Atot = d[19]; g.x0l = d[20]; g.half = (int)d[21];
+}
+// a wave-uniform 64-bit value moved to scalar registers
+__device__ __forceinline__ const void *bnr_uniform_ptr(const void *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const void *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double bnr_uniform_f64(double x)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+struct bnr_bp_chain { double *row; const double *prev; const double *a4, *Wbuf, *sz; double *Psum; long long *counters; unsigned long long seed; unsigned int it; int pad; };
+#define BNR_BPG_CT 8          // chains per workgroup
+#define BNR_BPG_WPC 1         // waves per chain in the draws: 2 WPC speculative attempts per draw and round
+__global__ __launch_bounds__(64 * BNR_BPG_CT * BNR_BPG_WPC) void k_backproj_group(const bnr_many chain_src, int s, int nchains)
+{
+    BNR_CRITICAL_PATH();
+    const bnr_dev &c0 = chain_src.at(0);                  // geometry, the shared X and index maps
+    constexpr int CT = BNR_BPG_CT, WPC = BNR_BPG_WPC, NT = 64 * CT * WPC, NW = CT * WPC, NSLOT = 2 * WPC;
+    static_assert(BNR_BPG_WPC == 1, "the draws below are wave-local: one wave per chain");
+    const int bid = blockIdx.x, cb = blockIdx.y * CT, nc = min(CT, nchains - cb);
+    const int R = c0.R, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_pad = c0.n_pad;
+    const int e0 = bid * c0.chunk_bp, ne = min(c0.chunk_bp, c0.q - e0);
+    const size_t ld = n_pad;
+#ifdef BNR_STAMPS
+#define BNR_GSTAMP(slot) do { if (tid == 0 && bid == 7 && blockIdx.y == 0) c0.dbg[330 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BNR_GSTAMP(slot) do { } while (0)
+#endif
+    BNR_GSTAMP(0);
+    extern __shared__ double sh[];
+    const int SA = max(max(n_pad, (3 * R + 1) * 33), 32 * 22), STR = SA + 33 * R + 32;
+    __shared__ bnr_bp_chain s_cd[CT];
+    __shared__ double s_val[CT][NSLOT][32];
+    __shared__ int s_acc[CT][NSLOT][32];
+    if (tid < nc) {
+        const bnr_dev &cd = chain_src.at(cb + tid);
+        const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
+        bnr_bp_chain t;
+        t.row = cd.trace + (size_t)P.row * cd.rowlen; t.prev = cd.trace + (size_t)P.prev * cd.rowlen;
+        t.a4 = cd.a4; t.Wbuf = cd.Wbuf; t.sz = cd.sz; t.Psum = cd.Psum; t.counters = cd.counters; t.seed = cd.seed; t.it = P.it; t.pad = 0;
+        s_cd[tid] = t;
+    }
+    __shared__ int s_el[32], s_ek[32];
+    if (tid >= 64 && tid < 96) { const int ee = tid - 64; s_el[ee] = ee < ne ? c0.el[e0 + ee] : 0; s_ek[ee] = ee < ne ? c0.ek[e0 + ee] : 0; }   // the same nodes for every chain
+    __syncthreads();
+    // u[r,l] u[r,k] of the block's edges (for the Lambda log-likelihoods at the end) and a4, per chain
+#pragma unroll 4
+    for (int it = tid; it < nc * R * 32; it += NT) {
+        const int c = it / (R * 32), idx = it - c * (R * 32), r = idx >> 5, ee = idx & 31;
+        const double *un0 = s_cd[c].row + c0.o_u;
+        const double v = un0[r + R * s_el[ee]] * un0[r + R * s_ek[ee]];
+        sh[c * STR + SA + r * 33 + ee] = ee < ne ? v : 0.0;
+    }
+    for (int it = tid; it < nc * n_pad; it += NT) { const int c = it / n_pad, i = it - c * n_pad; sh[c * STR + i] = s_cd[c].a4[i]; }
+    __syncthreads();
+    BNR_GSTAMP(1);
+    {
+        // wave w: columns w, w + NW, w + 2 NW, ... of the block, two at a time, for every chain; all loads of a 512-row stretch before the first multiply
+      for (int t0 = wave; t0 < 32; t0 += 2 * NW) {
+        const int t1 = t0 + NW;
+        double acc0[CT], acc1[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { acc0[c] = 0.0; acc1[c] = 0.0; }
+        const size_t o0 = (size_t)(e0 + (t0 < ne ? t0 : 0)) * ld, o1 = (size_t)(e0 + (t1 < ne ? t1 : 0)) * ld;
+#define BNR_BPG_DOTS(XP)                                                                                   \
+        for (int i0 = 0; i0 < n_pad; i0 += 512) {                                                         \
+            double x0[8], x1[8];                                                                          \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                               \
+                const int i = i0 + lane + 64 * j, ic = i < n_pad ? i : lane;                              \
+                x0[j] = (double)(XP)[o0 + ic]; x1[j] = (double)(XP)[o1 + ic];                             \
+            }                                                                                             \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                               \
+                /* branch-free: a row step past n_pad enters with x = 0 (acc + 0 a = acc), a chain past nc computes and is not stored */ \
+                const int i = i0 + lane + 64 * j;                                                         \
+                const bool in = i < n_pad;                                                                \
+                const int ii = in ? i : lane;                                                             \
+                const double xa = in ? x0[j] : 0.0, xb = in ? x1[j] : 0.0;                                \
+                _Pragma("unroll") for (int c = 0; c < CT; ++c) {                                          \
+                    const double av = sh[c * STR + ii]; acc0[c] = fma(xa, av, acc0[c]); acc1[c] = fma(xb, av, acc1[c]); \
+                }                                                                                         \
+            }                                                                                             \
+        }
+        if (c0.X8) { BNR_BPG_DOTS(c0.X8) } else { BNR_BPG_DOTS(c0.X) }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            if (c < nc) {
+                const double v0 = wave_sum(acc0[c]), v1 = wave_sum(acc1[c]);
+                if (lane == 0) { if (t0 < ne) sh[c * STR + SA + 33 * R + t0] = v0; if (t1 < ne) sh[c * STR + SA + 33 * R + t1] = v1; }
+            }
+        }
+      }
+    }
+    __syncthreads();
+    BNR_GSTAMP(2);
+    // update_D! for (chain c = wave / WPC, edge el32, attempt slot 0..2 WPC - 1): the first accepted attempt of the counter sequence wins
+    const int c = __builtin_amdgcn_readfirstlane(wave / WPC), el32 = lane & 31, slot = (wave % WPC) * 2 + (lane >> 5), e = e0 + el32;
+    const bool act = el32 < ne && c < nc;
+    // the chain's pointers and scalars are the same for the whole wave: kept in scalar registers (the draws below need every vector register)
+    bnr_bp_chain cc;
+    {
+        const bnr_bp_chain &m = s_cd[c < nc ? c : 0];
+        cc.row = (double *)bnr_uniform_ptr(m.row); cc.prev = (const double *)bnr_uniform_ptr(m.prev); cc.a4 = nullptr;
+        cc.Wbuf = (const double *)bnr_uniform_ptr(m.Wbuf); cc.sz = (const double *)bnr_uniform_ptr(m.sz);
+        cc.Psum = (double *)bnr_uniform_ptr(m.Psum); cc.counters = (long long *)bnr_uniform_ptr(m.counters);
+        cc.seed = (unsigned long long)bnr_uniform_ptr((const void *)m.seed); cc.it = (unsigned)__builtin_amdgcn_readfirstlane((int)m.it); cc.pad = 0;
+    }
+    double *row = cc.row;
+    const double *prev = cc.prev;
+    const double tau2 = bnr_uniform_f64(row[ROW_TAU2]), tau = sqrt(tau2);
+    double gam = 0.0, Snew = 1.0, W = 0.0;
+    int cap = 0;
+    if (act) {
+        W = cc.Wbuf[e];
+        const double Sp = prev[c0.o_S + e];
+        gam = tau * (cc.sz[e] + Sp * sh[c * STR + SA + 33 * R + el32]) + W;
+        if (slot == 0) row[c0.o_gamma + e] = gam;
+    }
+    {
+        const double g = gam - W, chi = (g * g) / tau2, psi = prev[ROW_THETA];
+        bnr_gig_ctx gc;
+        gc.kind = 4;
+        if (act) bnr_gig_setup(gc, 0.5, chi, psi);
+        const bool loop = act && (gc.kind == 2 || gc.kind == 3);
+        bool done = !loop;
+        // Round 1: attempts 0 and 1 of every edge (lanes 0..31 / 32..63).  Later rounds: the few edges that are still open share the
+        // wave's 64 lanes -- k = 64 / open attempts each, the contexts handed over through LDS -- so that the draws of a block end
+        // after two rounds instead of after as many as its unluckiest edge needs (the first accepted attempt of the counter
+        // sequence wins either way: the same draw).  One wave per chain: everything below is wave-local.
+        uint32_t base = 0;
+        {
+            double v = 0.0;
+            const bool ok = !done && bnr_gig_try(gc, cc.seed, cc.it, (uint32_t)e, (uint32_t)slot, v);
+            s_acc[c][slot][el32] = ok ? 1 : 0;
+            s_val[c][slot][el32] = v;
+            bnr_wsync();
+            if (!done) {
+#pragma unroll
+                for (int a = NSLOT - 1; a >= 0; --a) if (s_acc[c][a][el32]) { Snew = s_val[c][a][el32]; done = true; }   // lowest accepted attempt wins
+            }
+            bnr_wsync();
+            base = NSLOT;
+        }
+        double *sx = sh + c * STR;                                  // the chain's a4 area: [open edge][22] contexts
+        double *sv = &s_val[c][0][0];                               // 64 values
+        int *spe = &s_acc[c][0][0];                                 // open edge -> its index in the block
+        while (base < BNR_MAX_ATTEMPTS) {
+            const unsigned long long pm = __ballot(lane < 32 && !done);
+            const int npend = __popcll(pm);
+            if (npend == 0) break;
+            const int k = min(64 / npend, 32);
+            const int rank = __popcll(pm & ((1ull << el32) - 1ull));
+            if (lane < 32 && !done) { bnr_gig_ctx_put(gc, sx + rank * 22); spe[rank] = el32; }
+            bnr_wsync();
+            const int r = lane / k, sub = lane - r * k;
+            bool ok = false;
+            double v = 0.0;
+            if (r < npend) {
+                bnr_gig_ctx g2;
+                bnr_gig_ctx_get(g2, sx + r * 22);
+                ok = bnr_gig_try(g2, cc.seed, cc.it, (uint32_t)(e0 + spe[r]), base + (uint32_t)sub, v);
+            }
+            const unsigned long long om = __ballot(ok);
+            sv[lane] = v;
+            bnr_wsync();
+            if (!done) {
+                const unsigned long long mine = (om >> (rank * k)) & ((1ull << k) - 1ull);          // k <= 32
+                if (mine) { Snew = sv[rank * k + __ffsll((long long)mine) - 1]; done = true; }
+            }
+            bnr_wsync();
+            base += (uint32_t)k;
+        }
+        if (!done) { cap = 1; Snew = gc.alpha * gc.xm; }                      // attempt cap, as bnr_gig
+        if (act && !loop) Snew = bnr_gig_degenerate(gc, cc.seed, chi, psi, cc.it, (uint32_t)e, &cap);
+        if (act && slot == 0) row[c0.o_S + e] = Snew;
+    }
+    BNR_GSTAMP(3);
+    if ((wave % WPC) || c >= nc) return;
+    // partial sums of the block for chain c by its first wave (lanes 0..31 hold attempt slot 0 of the 32 edges), as in k_backproj
+    double *ps = cc.Psum + (size_t)bid * (1 + 3 * R);
+    double *st = sh + c * STR;                                  // the chain's a4 area is free now
+    const double *sdr = sh + c * STR + SA;
+    const double *lamp = prev + c0.o_lam;
+    const double sd = sqrt(tau2 * Snew), lsd = log(sd) + 0.5 * log(2.0 * BNR_PI);
+    if (lane < 32) {
+        st[lane] = act ? Snew : 0.0;
+        for (int r = 0; r < R; ++r) {
+            double dr = sdr[r * 33 + lane];
+            double lr = lamp[r];
+#pragma unroll
+            for (int q3 = 0; q3 < 3; ++q3) {
+                double Wc = W + (bnr_lambda_value(q3) - lr) * dr;
+                double zz = (gam - Wc) / sd;
+                st[(1 + 3 * r + q3) * 33 + lane] = act ? (-0.5 * zz * zz - lsd) : 0.0;
+            }
+        }
+    }
+    bnr_wsync();
+    for (int j = lane; j < 1 + 3 * R; j += 64) {
+        double acc = 0.0;
+#pragma unroll 8
+        for (int e2 = 0; e2 < 32; ++e2) acc += st[j * 33 + e2];
+        ps[j] = acc;
+    }
+    BNR_GSTAMP(4);
+    if (cap && lane < 32) atomicAdd((unsigned long long *)&cc.counters[2], 1ull);
+}
+
 // ===================================================================================== k_tail
 // One block of 1024 threads.  mask bits: 1 theta, 2 Delta, 4 M, 8 mu, 16 Lambda, 32 pi, 64 carried sums (rr, sig_q for
 // the next tau2), 128 ring wrap copy, 256 inv(M)/logdet M for the next k_node, 512 pre-draw the next tau2.

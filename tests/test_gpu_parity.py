@@ -1189,7 +1189,8 @@ def test_factorization_variants_are_bitwise_equal(gpu):
     sweeping waves per workgroup) and k_chol_step2 (two panels per launch; variant 3: the trailing matrix updated every other launch with K = 128) -- give bitwise the tables of the default right-looking
     path (gibbs.jl:434), alone and as members of a lockstep group, from graphs and eagerly; so does the default's first launch, which sums the
     Gram's K-split partial tiles itself (fuse_reduce), against the separate k_gram_reduce pass, and the group's X pass with one workgroup per
-    column chunk for all members (group_xpass) against the per-chain kernel.  (The persistent Gram k_gram8p and the
+    column chunk for all members (group_xpass) against the per-chain kernel, and so does the opt-in back-projection / GIG kernel with one workgroup
+    per block of edges for eight members (group_backproj: the later rounds of its rejection samplers share the wave among the open edges).  (The persistent Gram k_gram8p and the
     pipelined schedule that builds on it are checked the same way by tools/ab_factor.py, outside this suite: they poll device flags.)"""
     for (n, V, R) in [(70, 19, 5), (193, 30, 5), (64, 9, 2), (500, 40, 4), (1000, 12, 3)]:
         X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=7)
@@ -1197,6 +1198,7 @@ def test_factorization_variants_are_bitwise_equal(gpu):
         for name, opts in (("right", {"factor_variant": 0}), ("right, separate reduction pass", {"factor_variant": 0, "fuse_reduce": 0}),
                            ("right, separate reduction pass, eager", {"factor_variant": 0, "fuse_reduce": 0, "graph": 0}), ("right, eager", {"factor_variant": 0, "graph": 0}),
                            ("right, X pass per chain", {"factor_variant": 0, "group_xpass": 0}),
+                           ("right, back-projection for the group", {"factor_variant": 0, "group_backproj": 1}),
                            ("left", {"factor_variant": 1}), ("left, eager", {"factor_variant": 1, "graph": 0}),
                            ("two panels", {"factor_variant": 2}), ("two panels, eager", {"factor_variant": 2, "graph": 0}),
                            ("two panels, K = 128 trailing update", {"factor_variant": 3}), ("two panels, K = 128, eager", {"factor_variant": 3, "graph": 0})):

@@ -9,7 +9,9 @@ for nb in (1, 8):
     for ch in chains: ch.init_prior()
     r = bnr_amd.Group(chains) if nb > 1 else chains[0]
     r.run(2, 40, 40)
-    d = chains[0].debug_read(330).astype(np.int64)[320:324]
-    print("chains %d: dots %d | GIG %d | sums %d | total %d cycles (%.2f us)" % (nb, d[1]-d[0], d[2]-d[1], d[3]-d[2], d[3]-d[0], (d[3]-d[0]) / 2400.0))
+    full = chains[0].debug_read(340).astype(np.int64)
+    d, g = full[320:324], full[330:335]
+    print("chains %d, per-chain kernel: dots %d | GIG %d | sums %d | total %d cycles (%.2f us)" % (nb, d[1]-d[0], d[2]-d[1], d[3]-d[2], d[3]-d[0], (d[3]-d[0]) / 2400.0))
+    if g[4] > g[0] > 0: print("chains %d, group kernel: staging %d | dots %d | GIG %d | sums %d | total %d cycles (%.2f us)" % (nb, g[1]-g[0], g[2]-g[1], g[3]-g[2], g[4]-g[3], g[4]-g[0], (g[4]-g[0]) / 2400.0))
     if nb > 1: r.close()
     for ch in chains: ch.close()
