@@ -232,6 +232,12 @@ int bnr_chain_debug_copy(bnr_chain *chain, int32_t which, double *out, int64_t c
  *   "factor_variant" -1 (default): chosen by size -- 0 below n_pad = 1024, 3 from there on; 0: right-looking factorization, one
  *               32-column panel per launch (k_gram_reduce + k_chol_step); 1: left-looking (k_chol_ll); 2: right-looking, two panels per
  *               launch (k_chol_step2); 3: 2 with the whole trailing matrix updated at every other launch only (K = 128)
+ *   "fuse_reduce" 1 / -1 (default): launch 0 of the one-panel factorization also sums the Gram's K-split partial tiles (no k_gram_reduce
+ *               launch); 0: separate reduction pass
+ *   "group_xpass" 1 / -1 (default): a lockstep group whose members share the device copy of X (bnr_chain_create_like) runs ONE X pass
+ *               for all members (k_xpass_group); 0: one per member.  "group_backproj" 1: the same for the back-projection / GIG kernel
+ *               (default 0: measured no faster)
+ *   "spw_cap"   1..4 (default 4): super blocks per update workgroup of the factorization, at most (diagnostics)
  *   "pipeline"  1 (needs factor_variant 1): factorization beside the Gram (persistent Gram off the reserved CUs, gates per tile column)
  *   "gate_us"   how long a gate of the pipelined schedule polls before it gives up (default 3000)
  *   "byte_x"    (chains only) 0: the X passes read the f64 matrix although a byte image of X exists; 1 (default): the byte image
