@@ -56,6 +56,12 @@ struct bnr_exec {
     int fuse_reduce = -1;                               // -1 / 1: launch 0 of the one-panel factorization also sums the Gram's K-split partials (no k_gram_reduce launch); 0: separate pass
     int group_backproj = 0;                             // 1: the same for the back-projection / GIG kernel (opt-in: bitwise equal, measured no faster -- the block is bound by the latency of the draws' arithmetic)
     int group_xpass = -1;                               // -1 / 1: a group whose members share X runs the X pass with one workgroup per chunk for all chains; 0: per chain
+    int lin_debug = 0, lin_merge = 0;                   // lin_merge: one stream per part (its scalar branch in front of its Gram)
+    int lin = 0;                                        // >= 1: the linear schedule with that many phase-shifted parts (see capture_linear)
+    std::vector<hipStream_t> lstreams;                  // [2 p] critical chain, [2 p + 1] scalar branch of part p
+    unsigned long long *lflags = nullptr;               // the counters the streams meet through
+    struct lrung { int k, part, which; hipGraph_t graph; hipGraphExec_t gexec; };
+    std::vector<lrung> lladder;
     int spw_cap = 4;                                    // super blocks per update workgroup of the factorization, at most
     int factor_variant = -1;                            // -1: chosen by size; 0: right-looking k_chol_step (+ k_gram_reduce); 1: left-looking k_chol_ll
     int use_graph = 1, graph_k = 8;
@@ -520,6 +526,8 @@ static void drop_graph(bnr_exec &x)
 {
     for (auto &r : x.ladder) { if (r.gexec) (void)hipGraphExecDestroy(r.gexec); if (r.graph) (void)hipGraphDestroy(r.graph); }
     x.ladder.clear();
+    for (auto &r : x.lladder) { if (r.gexec) (void)hipGraphExecDestroy(r.gexec); if (r.graph) (void)hipGraphDestroy(r.graph); }
+    x.lladder.clear();
 }
 static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape)
 {
@@ -544,8 +552,12 @@ static void exec_free(bnr_exec &x)
     if (x.stream2) { (void)hipStreamSynchronize(x.stream2); }
     if (x.stream3) { (void)hipStreamSynchronize(x.stream3); (void)hipStreamDestroy(x.stream3); }
     if (x.stream4) { (void)hipStreamSynchronize(x.stream4); (void)hipStreamDestroy(x.stream4); }
+    for (hipStream_t st : x.lstreams) { (void)hipStreamSynchronize(st); }
     if (x.gctl) (void)hipFree(x.gctl);
     drop_graph(x);
+    for (hipStream_t st : x.lstreams) (void)hipStreamDestroy(st);
+    x.lstreams.clear();
+    if (x.lflags) (void)hipFree(x.lflags);
     if (x.stream) (void)hipStreamDestroy(x.stream);
     if (x.stream2) (void)hipStreamDestroy(x.stream2);
     for (hipEvent_t e : x.fj) (void)hipEventDestroy(e);
@@ -864,6 +876,103 @@ static int collect_gram_times(bnr_exec &x, int nsweeps)
     return BNR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------- linear schedule
+// The members of a group as `lin` parts (1, 2 or 4), every part with two streams -- C: ring gate, Gram, factorization, gate, solve,
+// back-projection; S: gate, the scalar branch -- and every stream replaying LINEAR graphs.  The parts are phase-shifted by a ring of
+// counters: part p's Gram of a sweep waits for part p-1's (part 0's for the last part's of the sweep before), so the matrix cores always
+// have exactly one Gram to run and every part's latency chains run beside the OTHER parts' Grams.  A chain's arithmetic does not depend
+// on who shares its launches: bitwise the same tables.
+//   lflags (device, unsigned long long): [0] sticky; [1] ring = Grams finished; per part p at 8 + 8 p: [0] back-projections finished, [1] rhs
+//   finished, [2] sweeps the C stream's graphs have advanced over, [3] the same for the S stream.
+static bnr_exec part_view(const bnr_exec &x, int first, int count, hipStream_t st)
+{
+    bnr_exec v = x;                                          // shallow: the view owns nothing
+    v.cds = x.cds + first; v.cds_pin = x.cds_pin + first; v.nb = count; v.stream = st;
+    v.ladder.clear(); v.fj.clear(); v.ev.clear(); v.lstreams.clear(); v.lladder.clear();
+    return v;
+}
+static void lin_parts(const bnr_exec &x, std::vector<int> &first)
+{
+    const int P = x.lin;
+    first.assign(P + 1, 0);
+    for (int p = 0; p < P; ++p) first[p + 1] = first[p] + (x.nb / P) + (p < x.nb % P ? 1 : 0);
+}
+static int capture_linear(bnr_exec &x, int K, int p, int which, hipGraph_t *graph, hipGraphExec_t *gexec)
+{
+    std::vector<int> first;
+    lin_parts(x, first);
+    const int P = x.lin, nbp = first[p + 1] - first[p];
+    hipStream_t st = x.lstreams[x.lin_merge ? p : 2 * p + which];
+    unsigned long long *lf = x.lflags, *pf = x.lflags + 8 + 8 * p;
+    long long *err = x.shape->counters + 8;
+    unsigned long long *dbg = x.lin_debug ? x.shape->dbg : nullptr;       // member 0's diagnostics buffer
+    bnr_exec v = part_view(x, first[p], nbp, st);
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int s = 0; s < K; ++s) {
+        if (which == 1) {
+            // S: the scalar branch, behind the part's back-projection of the sweep before
+            hipLaunchKernelGGL(k_lin_gate, dim3(1), dim3(64), 0, st, pf + 0, pf + 3, s, 1, 0, x.gate_us, lf, err, dbg, p, 0);
+            launch_tail(v, s - 1, 1023, 0);
+            launch_node(v, s, 3);
+            launch_xpass(v, s, 3);
+            launch_rhs(v, s);
+            hipLaunchKernelGGL(k_lin_set, dim3(1), dim3(64), 0, st, pf + 1, pf + 3, s, 1, 1, dbg, p, 1);
+        } else {
+            if (x.lin_merge) {
+                // one stream per part: its scalar branch in front of its Gram (the other parts' work runs beside both)
+                launch_tail(v, s - 1, 1023, 0);
+                launch_node(v, s, 3);
+                launch_xpass(v, s, 3);
+                launch_rhs(v, s);
+            }
+            // C: the Gram takes its turn in the ring, then the part's latency chain
+            if (P > 1) hipLaunchKernelGGL(k_lin_gate, dim3(1), dim3(64), 0, st, lf + 1, pf + 2, s, P, p, x.gate_us, lf, err, dbg, p, 2);
+            launch_gram(v, s, st, false);
+            if (P > 1) hipLaunchKernelGGL(k_lin_set, dim3(1), dim3(64), 0, st, lf + 1, pf + 2, s, P, p + 1, dbg, p, 3);
+            launch_chol(v, s, st);
+            if (!x.lin_merge) hipLaunchKernelGGL(k_lin_gate, dim3(1), dim3(64), 0, st, pf + 1, pf + 2, s, 1, 1, x.gate_us, lf, err, dbg, p, 4);
+            launch_solve(v);
+            launch_backproj(v, s, 7);
+            if (s == K - 1) hipLaunchKernelGGL(k_advance, dim3(nbp), dim3(1), 0, st, (const bnr_dev *)v.cds, K);   // before the hand-over: the S stream's next tail finds the new base
+            if (!x.lin_merge || dbg) hipLaunchKernelGGL(k_lin_set, dim3(1), dim3(64), 0, st, pf + 0, pf + 2, s, 1, 1, dbg, p, 5);
+        }
+    }
+    hipLaunchKernelGGL(k_lin_add, dim3(1), dim3(64), 0, st, pf + 2 + which, K);
+    HIPCHK(hipStreamEndCapture(st, graph));
+    HIPCHK(hipGraphInstantiate(gexec, *graph, nullptr, nullptr, 0));
+    (void)hipGraphUpload(*gexec, st);
+    (void)hipGetLastError();
+    return BNR_OK;
+}
+static bool linear_mode(const bnr_exec &x) { return x.lin >= 1 && x.nb >= x.lin && x.use_graph && !x.profiling && x.overlap && !x.lstreams.empty() && x.lflags; }
+static int linear_prepare(bnr_exec &x)
+{
+    if (!x.lladder.empty()) return BNR_OK;
+    for (int k = x.graph_k; k >= 1; k /= 2) {
+        for (int p = 0; p < x.lin; ++p)
+            for (int w = 0; w < (x.lin_merge ? 1 : 2); ++w) {
+                bnr_exec::lrung r{k, p, w, nullptr, nullptr};
+                int rc = capture_linear(x, k, p, w, &r.graph, &r.gexec);
+                x.lladder.push_back(r);
+                if (rc) { drop_graph(x); return rc; }
+            }
+    }
+    return BNR_OK;
+}
+// enqueue `count` sweeps on the 2 lin streams; the caller has made them wait for x.stream and joins them afterwards
+static int linear_range(bnr_exec &x, int count)
+{
+    int rc = linear_prepare(x);
+    if (rc) return rc;
+    std::vector<int> ks;
+    int done = 0;
+    for (int k = x.graph_k; k >= 1; k /= 2) while (count - done >= k) { ks.push_back(k); done += k; }
+    for (auto it = ks.rbegin(); it != ks.rend(); ++it)
+        for (const auto &r : x.lladder)
+            if (r.k == *it) HIPCHK(hipGraphLaunch(r.gexec, x.lstreams[x.lin_merge ? r.part : 2 * r.part + r.which]));
+    x.n_replayed += count;
+    return BNR_OK;
+}
 // Capture K sweeps (+ the plan-base advance) into a graph and instantiate it.  The kernels find their plan entry through
 // pbase at run time, so a captured graph serves every later batch.
 static int capture_sweeps(bnr_exec &x, int K, hipGraph_t *graph, hipGraphExec_t *gexec)
@@ -896,6 +1005,18 @@ static int exec_prepare(bnr_exec &x)
 static int launch_range(bnr_exec &x, int count)
 {
     int done = 0;
+    if (linear_mode(x) && x.graph_k > 0) {
+        // the lin streams start behind everything enqueued on x.stream so far and x.stream continues behind them
+        hipEvent_t e0 = nullptr;
+        HIPCHK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+        HIPNOTE(hipEventRecord(e0, x.stream));
+        const int nls = x.lin_merge ? x.lin : 2 * x.lin;
+        for (int i = 0; i < nls; ++i) HIPNOTE(hipStreamWaitEvent(x.lstreams[i], e0, 0));
+        int rc = linear_range(x, count);
+        for (int i = 0; i < nls; ++i) { HIPNOTE(hipEventRecord(e0, x.lstreams[i])); HIPNOTE(hipStreamWaitEvent(x.stream, e0, 0)); }
+        (void)hipEventDestroy(e0);
+        return rc;
+    }
     if (x.use_graph && !x.profiling && x.graph_k > 0) {     // profiling records HIP events around k_gram: eager launches
         int rc = exec_prepare(x);
         if (rc) return rc;
@@ -1020,6 +1141,7 @@ static int run_exec(bnr_exec &x, int first_index, int count, int prog_freq, bnr_
 {
     int rc;
     hipLaunchKernelGGL(k_setbase, dim3(x.nb), dim3(1), 0, x.stream, (const bnr_dev *)x.cds, 1);
+    if (x.lflags) HIPCHK(hipMemsetAsync(x.lflags, 0, sizeof(unsigned long long) * 64, x.stream));
     x.t_gram_acc = 0; x.n_gram = 0; x.n_replayed = 0; x.n_eager = 0;
     hipEvent_t r0 = nullptr, r1 = nullptr;
     if (x.profiling) { HIPCHK(hipEventCreate(&r0)); HIPCHK(hipEventCreate(&r1)); HIPNOTE(hipEventRecord(r0, x.stream)); }
@@ -1189,6 +1311,22 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
     if (!strcmp(name, "group_xpass")) {
         if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "group_xpass must be -1 (default: on), 0 or 1");
         x.group_xpass = (int)value; drop_graph(x); return BNR_OK;
+    }
+    if (!strcmp(name, "linear_merge")) { x.lin_merge = (int)value; drop_graph(x); return BNR_OK; }
+    if (!strcmp(name, "linear_debug")) { x.lin_debug = (int)value; drop_graph(x); return BNR_OK; }
+    if (!strcmp(name, "linear")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return fail(BNR_ERR_BAD_ARG, "linear must be 0 (off), 1, 2 or 4 (parts)");
+        HIPCHK(hipSetDevice(x.device));
+        HIPCHK(hipStreamSynchronize(x.stream));
+        drop_graph(x);
+        while ((int)x.lstreams.size() < (x.lin_merge ? 1 : 2) * (int)value) {
+            hipStream_t st = nullptr;
+            HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            x.lstreams.push_back(st);
+        }
+        if (value && !x.lflags) { HIPCHK(hipMalloc((void **)&x.lflags, sizeof(unsigned long long) * 64)); HIPCHK(hipMemset(x.lflags, 0, sizeof(unsigned long long) * 64)); }
+        x.lin = (int)value;
+        return BNR_OK;
     }
     if (!strcmp(name, "spw_cap")) {
         if (value < 1 || value > 4) return fail(BNR_ERR_BAD_ARG, "spw_cap must be 1..4");

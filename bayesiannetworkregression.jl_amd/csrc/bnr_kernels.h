@@ -2750,6 +2750,41 @@ __global__ __launch_bounds__(1024) void k_tail(const SRC chain_src, int s, int m
 // advances the plan base after a batch of sweeps (last node of the captured graph)
 __global__ void k_advance(const bnr_dev *cds, int by) { if (threadIdx.x == 0) ((int *)cds[blockIdx.x].pbase)[0] += by; }   // grid = chains
 __global__ void k_nop() { }
+// ---- "linear" schedule: every stream of the sweep replays a LINEAR captured graph (linear graphs on different streams run side by side; graphs
+// with forked branches do not, and their branches are mapped to queues in ways one cannot steer -- tools/graph_concurrency_probe.hip), and the
+// streams meet through counters in device memory: a one-wave gate kernel in front of the consumer, a one-thread kernel behind the producer.
+// Both are ordinary kernels of their streams, so the data itself travels by kernel boundaries (release at the producer's end, acquire at the
+// consumer's start); the counter is written and read past the L2s (sc1).  lf[0] = sticky "a gate gave up" word.
+// dbg (diagnostics, may be null): entry / exit times of the gates and setters, a ring over 16 sweeps: [((n & 15) 4 + part) 12 + 2 kind + {0, 1}]
+__global__ void k_lin_set(unsigned long long *flag, const unsigned long long *cnt, int s, int mul, int add, unsigned long long *dbg, int part, int kind)
+{
+    if (threadIdx.x != 0) return;
+    if (dbg) dbg[(((cnt[0] + s) & 15) * 4 + part) * 12 + 2 * kind] = __builtin_amdgcn_s_memrealtime();
+    __hip_atomic_store(flag, (cnt[0] + (unsigned long long)s) * (unsigned long long)mul + (unsigned long long)add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_lin_add(unsigned long long *cnt, int by) { if (threadIdx.x == 0) cnt[0] += (unsigned long long)by; }
+__global__ __launch_bounds__(64) void k_lin_gate(const unsigned long long *flag, const unsigned long long *cnt, int s, int mul, int add, int spin_us, unsigned long long *sticky, long long *err_counter,
+                                                  unsigned long long *dbg, int part, int kind)
+{
+    if (threadIdx.x != 0) return;
+    unsigned long long *d = dbg ? dbg + (((cnt[0] + s) & 15) * 4 + part) * 12 + 2 * kind : nullptr;
+    if (d) d[0] = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long need = (cnt[0] + (unsigned long long)s) * (unsigned long long)mul + (unsigned long long)add;
+    unsigned long long have = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (have >= need) { if (d) d[1] = __builtin_amdgcn_s_memrealtime(); return; }
+    if (__hip_atomic_load(sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) {
+        __builtin_amdgcn_s_setprio(3);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), lim = 100ull * (unsigned long long)spin_us;
+        do {
+            __builtin_amdgcn_s_sleep(4);
+            have = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while (have < need && __builtin_amdgcn_s_memrealtime() - t0 < lim);
+        if (have >= need) { if (d) d[1] = __builtin_amdgcn_s_memrealtime(); return; }
+        __hip_atomic_store(sticky, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    atomicAdd((unsigned long long *)err_counter, 1ull);           // counters[8]: "stream ordering violated" -- the run fails loudly
+}
+
 __global__ void k_stamp(unsigned long long *dbg, int slot) { if (threadIdx.x == 0) dbg[slot] = __builtin_amdgcn_s_memrealtime(); }
 // the event counters of all members of a launch into one block (one device -> host copy per run call); grid = chains, 16 threads
 __global__ void k_gather_counters(const bnr_dev *cds, long long *out) { out[blockIdx.x * 16 + threadIdx.x] = cds[blockIdx.x].counters[threadIdx.x]; }

@@ -238,6 +238,11 @@ int bnr_chain_debug_copy(bnr_chain *chain, int32_t which, double *out, int64_t c
  *               for all members (k_xpass_group); 0: one per member.  "group_backproj" 1: the same for the back-projection / GIG kernel
  *               (default 0: measured no faster)
  *   "spw_cap"   1..4 (default 4): super blocks per update workgroup of the factorization, at most (diagnostics)
+ *   "linear"    (groups; opt-in, experimental) 1 / 2 / 4: every stream replays LINEAR captured graphs and the streams meet through device
+ *               counters (gate / setter kernels); with 2 or 4 the members advance as that many phase-shifted parts, one part's Gram beside
+ *               the others' factorizations.  "linear_merge" 1 (set BEFORE "linear"): one stream per part.  Bitwise the default's tables;
+ *               measured no faster (profiles/round3_experiments_notes.txt I); needs its streams on distinct hardware queues (four exist) --
+ *               otherwise the run ends with "stream ordering violated".  0 (default): off
  *   "pipeline"  1 (needs factor_variant 1): factorization beside the Gram (persistent Gram off the reserved CUs, gates per tile column)
  *   "gate_us"   how long a gate of the pipelined schedule polls before it gives up (default 3000)
  *   "byte_x"    (chains only) 0: the X passes read the f64 matrix although a byte image of X exists; 1 (default): the byte image
