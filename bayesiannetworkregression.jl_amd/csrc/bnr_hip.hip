@@ -56,6 +56,8 @@ struct bnr_exec {
     int fuse_reduce = -1;                               // -1 / 1: launch 0 of the one-panel factorization also sums the Gram's K-split partials (no k_gram_reduce launch); 0: separate pass
     int group_backproj = 0;                             // 1: the same for the back-projection / GIG kernel (opt-in: bitwise equal, measured no faster -- the block is bound by the latency of the draws' arithmetic)
     int group_xpass = -1;                               // -1 / 1: a group whose members share X runs the X pass with one workgroup per chunk for all chains; 0: per chain
+    bnr_plan_entry *gplan_pin = nullptr, *gplan_dev = nullptr;   // groups: the members' plans of a run call, staged for one copy
+    int gplan_cap = 0;                                  // entries per member in there
     int lin_debug = 0, lin_merge = 0;                   // lin_merge: one stream per part (its scalar branch in front of its Gram)
     int lin = 0;                                        // >= 1: the linear schedule with that many phase-shifted parts (see capture_linear)
     std::vector<hipStream_t> lstreams;                  // [2 p] critical chain, [2 p + 1] scalar branch of part p
@@ -562,6 +564,8 @@ static void exec_free(bnr_exec &x)
     if (x.stream2) (void)hipStreamDestroy(x.stream2);
     for (hipEvent_t e : x.fj) (void)hipEventDestroy(e);
     for (hipEvent_t e : x.ev) (void)hipEventDestroy(e);
+    if (x.gplan_pin) (void)hipHostFree(x.gplan_pin);
+    if (x.gplan_dev) (void)hipFree(x.gplan_dev);
     if (x.cds) (void)hipFree(x.cds);
     if (x.cds_pin) (void)hipHostFree(x.cds_pin);
     if (x.status_dev) (void)hipFree(x.status_dev);
@@ -1092,7 +1096,7 @@ int bnr_chain_init_prior(bnr_chain *c)
 }
 
 // run! (gibbs.jl:849-864): builds the plan exactly as the reference loop walks (i, j), then enqueues the sweeps.
-static int enqueue_run(bnr_chain *c, int first_index, int nburn, int total, int purge_burn, hipStream_t st)
+static int enqueue_run(bnr_chain *c, int first_index, int nburn, int total, int purge_burn, hipStream_t st, bool upload = true)
 {
     if (first_index < 2 || total < first_index - 1) return fail(BNR_ERR_BAD_ARG, "need first_index>=2 and total>=first_index-1");
     HIPCHK(hipSetDevice(c->device));
@@ -1128,8 +1132,10 @@ static int enqueue_run(bnr_chain *c, int first_index, int nburn, int total, int 
         c->plan_pin[s] = e;
     }
     if (maxrow > c->d.tot) { c->iter -= count; return fail(BNR_ERR_BAD_ARG, "run would write past the table (tot_save too small)"); }
-    rc = upload_plan(c, count + 1, st);                // the caller sets the plan base of all members with ONE k_setbase launch
-    if (rc) return rc;
+    if (upload) {                                      // (a group stages all members' plans in one copy: upload_group_plans)
+        rc = upload_plan(c, count + 1, st);            // the caller sets the plan base of all members with ONE k_setbase launch
+        if (rc) return rc;
+    }
     c->next_row = j;
     c->carried_row = -1;
     return BNR_OK;
@@ -1246,6 +1252,32 @@ static int upload_members(bnr_group *g)
     return BNR_OK;
 }
 
+// all members' plans of a run call: one pinned staging buffer, ONE host-to-device copy, handed out by a kernel (after upload_members: it reads
+// the members' plan pointers from the device descriptors); the plan bases are set by run_exec's k_setbase
+static int upload_group_plans(bnr_group *g, int count)
+{
+    bnr_exec &x = g->x;
+    const int nb = (int)g->m.size();
+    if (x.gplan_cap < count) {
+        if (x.gplan_pin) (void)hipHostFree(x.gplan_pin);
+        if (x.gplan_dev) (void)hipFree(x.gplan_dev);
+        x.gplan_pin = nullptr; x.gplan_dev = nullptr; x.gplan_cap = 0;
+        const int cap = std::max(count, 64) * 2;
+        HIPCHK(hipHostMalloc((void **)&x.gplan_pin, sizeof(bnr_plan_entry) * (size_t)cap * nb));
+        HIPCHK(hipMalloc((void **)&x.gplan_dev, sizeof(bnr_plan_entry) * (size_t)cap * nb));
+        x.gplan_cap = cap;
+    } else HIPCHK(hipStreamSynchronize(x.stream));          // the staging buffer of the previous call has been consumed
+    for (int i = 0; i < nb; ++i) memcpy(x.gplan_pin + (size_t)i * x.gplan_cap, g->m[i]->plan_pin, sizeof(bnr_plan_entry) * count);
+    // one copy of the used part of every member's slot (the slots are gplan_cap apart: copy the whole span when it is small, else per member)
+    if ((size_t)x.gplan_cap * nb <= 4 * (size_t)count * nb)
+        HIPCHK(hipMemcpyAsync(x.gplan_dev, x.gplan_pin, sizeof(bnr_plan_entry) * (size_t)x.gplan_cap * nb, hipMemcpyHostToDevice, x.stream));
+    else
+        for (int i = 0; i < nb; ++i)
+            HIPCHK(hipMemcpyAsync(x.gplan_dev + (size_t)i * x.gplan_cap, x.gplan_pin + (size_t)i * x.gplan_cap, sizeof(bnr_plan_entry) * count, hipMemcpyHostToDevice, x.stream));
+    hipLaunchKernelGGL(k_scatter_plans, dim3(nb), dim3(256), 0, x.stream, (const bnr_dev *)x.cds, (const bnr_plan_entry *)x.gplan_dev, x.gplan_cap, count);
+    return BNR_OK;
+}
+
 int bnr_group_run(bnr_group *g, int32_t first_index, int32_t nburn, int32_t total, int32_t purge_burn,
                   int32_t prog_freq, bnr_progress_cb cb, void *user, int32_t *next_row)
 {
@@ -1260,11 +1292,13 @@ int bnr_group_run(bnr_group *g, int32_t first_index, int32_t nburn, int32_t tota
     const int count = total - first_index + 1;
     int rc;
     for (bnr_chain *c : g->m) {
-        rc = enqueue_run(c, first_index, nburn, total, purge_burn, g->x.stream);     // every member walks the same (i, j) schedule
+        rc = enqueue_run(c, first_index, nburn, total, purge_burn, g->x.stream, false);     // every member walks the same (i, j) schedule
         if (rc) return rc;
     }
     if (count <= 0) { if (next_row) *next_row = g->m[0]->next_row; return BNR_OK; }
     rc = upload_members(g);
+    if (rc) return rc;
+    rc = upload_group_plans(g, count + 1);
     if (rc) return rc;
     rc = run_exec(g->x, first_index, count, prog_freq, cb, user);
     if (rc) return rc;

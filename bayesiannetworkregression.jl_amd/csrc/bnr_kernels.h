@@ -2749,6 +2749,13 @@ __global__ __launch_bounds__(1024) void k_tail(const SRC chain_src, int s, int m
 
 // advances the plan base after a batch of sweeps (last node of the captured graph)
 __global__ void k_advance(const bnr_dev *cds, int by) { if (threadIdx.x == 0) ((int *)cds[blockIdx.x].pbase)[0] += by; }   // grid = chains
+// the members' plans of a run call arrive in ONE staged copy and are handed out on the device (a copy per member cost ~20 us each on the stream)
+__global__ void k_scatter_plans(const bnr_dev *cds, const bnr_plan_entry *staged, int stride, int count)
+{
+    bnr_plan_entry *dst = (bnr_plan_entry *)cds[blockIdx.x].plan;
+    const bnr_plan_entry *src = staged + (size_t)blockIdx.x * stride;
+    for (int e = threadIdx.x; e < count; e += blockDim.x) dst[e] = src[e];
+}
 __global__ void k_nop() { }
 // ---- "linear" schedule: every stream of the sweep replays a LINEAR captured graph (linear graphs on different streams run side by side; graphs
 // with forked branches do not, and their branches are mapped to queues in ways one cannot steer -- tools/graph_concurrency_probe.hip), and the
