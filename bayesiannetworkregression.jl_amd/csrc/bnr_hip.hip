@@ -661,7 +661,10 @@ static bool group_shares_x(const bnr_exec &x)
 }
 static void launch_xpass(bnr_exec &x, int s, int which)
 {
-    if (which == 3 && x.group_xpass != 0 && group_shares_x(x) && 16 * (size_t)x.shape->chunk_x * sizeof(double) <= 48 * 1024) {
+    // by default only where X is large (>= 8 MB per chain): the point is the L2 traffic beside the panel steps; small problems are chains of
+    // latencies, and there the per-chain kernel's many small workgroups finish sooner (n = 200, V = 50: 125.8 vs 139.4 us per sweep of 8 chains)
+    const bool big_x = (size_t)x.shape->n_pad * x.shape->q * sizeof(double) >= ((size_t)8 << 20);
+    if (which == 3 && (x.group_xpass == 1 || (x.group_xpass < 0 && big_x)) && group_shares_x(x) && 16 * (size_t)x.shape->chunk_x * sizeof(double) <= 48 * 1024) {
         // one workgroup per column chunk and row slice for all members: X comes out of the L2s once, not once per chain
         hipLaunchKernelGGL(k_xpass_group, dim3(x.shape->nblk_x * ((x.shape->n_pad + 255) / 256)), dim3(256), 16 * x.shape->chunk_x * sizeof(double), x.stream, bnr_many{x.cds}, s, x.nb);
         return;

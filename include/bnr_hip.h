@@ -234,8 +234,8 @@ int bnr_chain_debug_copy(bnr_chain *chain, int32_t which, double *out, int64_t c
  *               launch (k_chol_step2); 3: 2 with the whole trailing matrix updated at every other launch only (K = 128)
  *   "fuse_reduce" 1 / -1 (default): launch 0 of the one-panel factorization also sums the Gram's K-split partial tiles (no k_gram_reduce
  *               launch); 0: separate reduction pass
- *   "group_xpass" 1 / -1 (default): a lockstep group whose members share the device copy of X (bnr_chain_create_like) runs ONE X pass
- *               for all members (k_xpass_group); 0: one per member.  "group_backproj" 1: the same for the back-projection / GIG kernel
+ *   "group_xpass" -1 (default): a lockstep group whose members share the device copy of X (bnr_chain_create_like) runs ONE X pass
+ *               for all members (k_xpass_group) when X has 8 MB or more per chain; 1: always; 0: one pass per member.  "group_backproj" 1: the same for the back-projection / GIG kernel
  *               (default 0: measured no faster)
  *   "spw_cap"   1..4 (default 4): super blocks per update workgroup of the factorization, at most (diagnostics)
  *   "linear"    (groups; opt-in, experimental) 1 / 2 / 4: every stream replays LINEAR captured graphs and the streams meet through device

@@ -1198,6 +1198,7 @@ def test_factorization_variants_are_bitwise_equal(gpu):
         for name, opts in (("right", {"factor_variant": 0}), ("right, separate reduction pass", {"factor_variant": 0, "fuse_reduce": 0}),
                            ("right, separate reduction pass, eager", {"factor_variant": 0, "fuse_reduce": 0, "graph": 0}), ("right, eager", {"factor_variant": 0, "graph": 0}),
                            ("right, X pass per chain", {"factor_variant": 0, "group_xpass": 0}),
+                           ("right, X pass for the group", {"factor_variant": 0, "group_xpass": 1}),
                            ("right, back-projection for the group", {"factor_variant": 0, "group_backproj": 1}),
                            ("left", {"factor_variant": 1}), ("left, eager", {"factor_variant": 1, "graph": 0}),
                            ("two panels", {"factor_variant": 2}), ("two panels, eager", {"factor_variant": 2, "graph": 0}),
