@@ -731,7 +731,10 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
         // workgroups than two per CU.  A launch that fits in one round (one chain: 252 workgroups at the headline size) never reaches
         // that occupancy and is better off with k_gram's 16-column batches = half the barriers (33.5 vs 36.0 us; n=500, V=300: 228 vs 237).
         const bool wide = x.gram_variant ? x.gram_variant == 16 : ((long)x.nb * ntl * d.ksplit <= 2L * x.ncu);
-        if (!wide) {
+        if (x.gram_variant == 10) {                        // experiment: the unscaled panel by LDS-DMA
+            if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8d<bnr_one>), ggrid, dim3(512), 0, st, bnr_one{d}, s, 1);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8d<bnr_many>), ggrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb);
+        } else if (!wide) {
             if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8<bnr_one>), ggrid, dim3(512), 0, st, bnr_one{d}, s, 1);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8<bnr_many>), ggrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb);
         } else {
@@ -1334,7 +1337,7 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
     if (!strcmp(name, "graph")) { x.use_graph = (int)value; return BNR_OK; }
     if (!strcmp(name, "overlap")) { x.overlap = (int)value; drop_graph(x); return BNR_OK; }
     if (!strcmp(name, "gram_variant")) {
-        if (value != 0 && value != 8 && value != 9 && value != 16) return fail(BNR_ERR_BAD_ARG, "gram_variant must be 0 (auto), 8, 9 (persistent) or 16");
+        if (value != 0 && value != 8 && value != 9 && value != 10 && value != 16) return fail(BNR_ERR_BAD_ARG, "gram_variant must be 0 (auto), 8, 9 (persistent), 10 (LDS-DMA experiment) or 16");
         x.gram_variant = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "fuse_reduce")) {

@@ -784,6 +784,114 @@ __device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const do
         }
     }
 }
+// k_gram8d: k_gram8 with the UNSCALED panel (the j side) moved global -> LDS by the DMA path (global_load_lds_dwordx4: no vector registers, no
+// ds_write; the scaled i side still travels through registers, it is multiplied by S on the way).  The DMA lands in lane order, so lane l of
+// K-group wave w asks for the rows that belong at image position (column 2 w + l / 32, row pair l % 32) -- the XOR swizzle of the odd columns is
+// applied to the GLOBAL row.  Three j buffers (the DMA of batch b + 2 is issued while batch b is multiplied), two i buffers as before:
+// 40 KiB of LDS, three workgroups per CU.  Bitwise the partial tiles of k_gram8 (same data, same order).  gram_variant 10 (experiment).
+template <bool WT>
+__device__ __forceinline__ void bnr_gram8_task_dma(const bnr_gram_geom &cd, const double *Sp, double *Gpart, int t, int ti, int tj, int ks, double *sred)
+{
+    constexpr int KG = 2, KB = 8;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kg = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1, wq = wave & 3;
+    const int kchunk = cd.q_pad / cd.ksplit, ksub = kchunk / KG, eb = ks * kchunk + kg * ksub, nbatch = ksub / KB;
+    const size_t ld = cd.n_pad;
+    const int li = lane & 15, lk = lane >> 4;
+    const int tg = tid & 255, c = tg >> 5, rp = tg & 31;
+    const unsigned offI = (unsigned)(ti * BNR_GT + 2 * rp) + (unsigned)c * (unsigned)ld;
+    const unsigned offJ = (unsigned)(tj * BNR_GT + ((2 * rp) ^ ((c & 1) << 4))) + (unsigned)c * (unsigned)ld;     // the row that belongs at this lane's image position
+    const double *xb = cd.X + (size_t)eb * ld;
+    const double *sb = Sp + eb;
+    const int smax = cd.q - 1 - eb;
+    constexpr int PANEL = KB * BNR_GT;
+    double *stg = sred + (size_t)kg * (5 * PANEL);     // [I buf 0][I buf 1][J buf 0][J buf 1][J buf 2]
+    const int woff = c * BNR_GT + ((2 * rp) ^ ((c & 1) << 4));
+    const int sw = (lk & 1) << 4;
+    const int ra0 = (wj * 32 + li) ^ sw, ra1 = (wj * 32 + 16 + li) ^ sw, rb0 = (wi * 32 + li) ^ sw, rb1 = (wi * 32 + 16 + li) ^ sw;
+    bnr_d4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
+    bnr_d2 ri;
+    double sv;
+    // this wave's 1 KiB of a J buffer: columns 2 wq and 2 wq + 1
+    const unsigned jlds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) void *)(stg + 2 * PANEL + (size_t)(2 * wq) * BNR_GT));
+#define BNR_G8D_LOAD(BIDX, JB)                                                                                   \
+    do {                                                                                                          \
+        const double *cb_ = xb + (size_t)(BIDX) * (KB * ld);                                                      \
+        const int si_ = (BIDX) * KB + c;                                                                          \
+        sv = sb[si_ < smax ? si_ : smax];                                                                         \
+        ri = *(const bnr_d2 *)(cb_ + offI);                                                                       \
+        /* as inline assembly: through the builtin the compiler drains vmcnt to 0 in front of every barrier (it knows the LDS is written) */ \
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(jlds0 + (unsigned)(JB) * (unsigned)(PANEL * sizeof(double))), "v"(cb_ + offJ) : "memory"); \
+    } while (0)
+#define BNR_G8D_STORE(BUF) do { *(bnr_d2 *)(stg + (size_t)(BUF) * PANEL + woff) = ri * sv; } while (0)
+#define BNR_G8D_COMPUTE(BUF, JB, K2)                                                          \
+    do {                                                                                      \
+        const double *bufI = stg + (size_t)(BUF) * PANEL, *bufJ = stg + (size_t)(2 + (JB)) * PANEL; \
+        const int kk = (4 * (K2) + lk) * BNR_GT;                                              \
+        double a0 = bufJ[kk + ra0], a1 = bufJ[kk + ra1];                                      \
+        double b0 = bufI[kk + rb0], b1 = bufI[kk + rb1];                                      \
+        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);                     \
+        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);                     \
+        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);                     \
+        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);                     \
+    } while (0)
+    int j0 = 0, j1 = 1, j2 = 2;                        // J buffers of batch b, b + 1, b + 2
+    BNR_G8D_LOAD(0, 0);
+    BNR_G8D_STORE(0);
+    BNR_G8D_LOAD(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int b = 0; b < nbatch; ++b) {
+        BNR_G8D_COMPUTE(b & 1, j0, 0);
+        BNR_G8D_STORE((b + 1) & 1);
+        BNR_G8D_LOAD(b + 2, j2);
+        BNR_G8D_COMPUTE(b & 1, j0, 1);
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // the DMA of batch b + 1 (issued one iteration ago) has landed: three VMEM operations were issued after it
+        __syncthreads();
+        const int jt = j0; j0 = j1; j1 = j2; j2 = jt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may still be in flight when the LDS is reused below
+    __syncthreads();
+    const int jb = wj * 32 + (lane >> 4), ib = wi * 32 + (lane & 15);
+    if (kg == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sred[(jb + 4 * r) * BNR_GT + ib] = c00[r];
+            sred[(jb + 4 * r) * BNR_GT + ib + 16] = c01[r];
+            sred[(jb + 16 + 4 * r) * BNR_GT + ib] = c10[r];
+            sred[(jb + 16 + 4 * r) * BNR_GT + ib + 16] = c11[r];
+        }
+    }
+    __syncthreads();
+    if (kg == 0) {
+        double *out = Gpart + ((size_t)ks * (cd.ntile * (cd.ntile + 1) / 2) + t) * (BNR_GT * BNR_GT);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bnr_gstore<WT>(out + (jb + 4 * r) * BNR_GT + ib, c00[r] + sred[(jb + 4 * r) * BNR_GT + ib]);
+            bnr_gstore<WT>(out + (jb + 4 * r) * BNR_GT + ib + 16, c01[r] + sred[(jb + 4 * r) * BNR_GT + ib + 16]);
+            bnr_gstore<WT>(out + (jb + 16 + 4 * r) * BNR_GT + ib, c10[r] + sred[(jb + 16 + 4 * r) * BNR_GT + ib]);
+            bnr_gstore<WT>(out + (jb + 16 + 4 * r) * BNR_GT + ib + 16, c11[r] + sred[(jb + 16 + 4 * r) * BNR_GT + ib + 16]);
+        }
+    }
+}
+template <class SRC>
+__global__ __launch_bounds__(512, 6) void k_gram8d(const SRC chain_src, int s, int nchains)
+{
+    const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
+    const int gchain = gr % nchains, gslot = (gr / nchains) * 8 + gx;
+    const bnr_dev &cd = chain_src.at(gchain);
+    __shared__ double sred[2 * 5 * 8 * BNR_GT];       // 40 KiB: staging buffers during the loop, then K-group 1's tile (32 KiB of it)
+    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
+    const double *Sp = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
+    if (gslot >= cd.ksplit * (cd.ntile * (cd.ntile + 1) / 2)) return;
+    const int task = cd.gmap[gslot];
+    int t = task & 0xFFFF, ti = 0;
+    const int ks = task >> 16;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    int tj = t - ti * (ti + 1) / 2;
+    bnr_gram8_task_dma<false>(bnr_geom_of(cd), Sp, cd.Gpart, t, ti, tj, ks, sred);
+    bnr_gram_count(cd, tj);
+}
 struct bnr_gramq { int qoff[9]; };                    // per-XCD task list x = gmapc[qoff[x] .. qoff[x+1])
 template <class SRC>
 __global__ __launch_bounds__(512, 6) void k_gram8(const SRC chain_src, int s, int nchains)
