@@ -64,6 +64,7 @@ struct bnr_exec {
     unsigned long long *lflags = nullptr;               // the counters the streams meet through
     struct lrung { int k, part, which; hipGraph_t graph; hipGraphExec_t gexec; };
     std::vector<lrung> lladder;
+    int split_sums = -1;                                 // 1: the back-projection's partial sums as a launch of their own in front of the scalar tail (off the critical chain)
     int spw_cap = 4;                                    // super blocks per update workgroup of the factorization, at most
     int factor_variant = -1;                            // -1: chosen by size; 0: right-looking k_chol_step (+ k_gram_reduce); 1: left-looking k_chol_ll
     int use_graph = 1, graph_k = 8;
@@ -813,6 +814,17 @@ static void launch_backproj(bnr_exec &x, int s, int flags)
 }
 static void launch_tail(bnr_exec &x, int s, int mask, int xg_src)
 { BNR_LAUNCH(k_tail, dim3(1, 1, x.nb), dim3(1024), (size_t)x.shape->R * x.shape->V * sizeof(double), x.stream, x, s, mask, xg_src); }
+// The scalar tail of sweep s with everything it needs: with split_sums the per-block partial sums of update_theta! / update_Lambda!
+// (gibbs.jl:476, 603-605) are not computed by the back-projection on the critical chain but by a launch of their own in front of the tail --
+// the same kernel with flags = 4, the same sums in the same order.
+// By default for a chain alone (its scalar branch has slack: one chain -3 us per sweep at the headline size, -7 at n = 2000); a group's scalar branch
+// is nearly critical already (8 chains: +32 us).
+static bool split_sums(const bnr_exec &x) { return x.split_sums == 1 || (x.split_sums < 0 && x.nb == 1); }
+static void launch_full_tail(bnr_exec &x, int s)
+{
+    if (split_sums(x)) launch_backproj(x, s, 4);
+    launch_tail(x, s, 1023, 0);
+}
 static hipEvent_t next_event(bnr_exec &x)
 {
     if (x.fj_next >= x.fj.size()) {
@@ -863,14 +875,14 @@ static void launch_sweep(bnr_exec &x, int s, bool prev_tail)
         launch_chol(x, s, sb);
         HIPNOTE(hipEventRecord(ej[0] = next_event(x), x.stream2));
     }
-    if (prev_tail) launch_tail(x, s - 1, 1023, 0);
+    if (prev_tail) launch_full_tail(x, s - 1);
     launch_node(x, s, 3);
     launch_xpass(x, s, 3);
     launch_rhs(x, s);
     if (overlap) { for (hipEvent_t e : ej) if (e) HIPNOTE(hipStreamWaitEvent(x.stream, e, 0)); }
     else { launch_gram(x, s, sb, timed); launch_chol(x, s, sb); }
     launch_solve(x);
-    launch_backproj(x, s, 7);
+    launch_backproj(x, s, split_sums(x) ? 3 : 7);
 }
 
 // with profiling on: after a batch, read the HIP events recorded around the k_gram launches of that batch (recorded on
@@ -922,7 +934,7 @@ static int capture_linear(bnr_exec &x, int K, int p, int which, hipGraph_t *grap
         if (which == 1) {
             // S: the scalar branch, behind the part's back-projection of the sweep before
             hipLaunchKernelGGL(k_lin_gate, dim3(1), dim3(64), 0, st, pf + 0, pf + 3, s, 1, 0, x.gate_us, lf, err, dbg, p, 0);
-            launch_tail(v, s - 1, 1023, 0);
+            launch_full_tail(v, s - 1);
             launch_node(v, s, 3);
             launch_xpass(v, s, 3);
             launch_rhs(v, s);
@@ -930,7 +942,7 @@ static int capture_linear(bnr_exec &x, int K, int p, int which, hipGraph_t *grap
         } else {
             if (x.lin_merge) {
                 // one stream per part: its scalar branch in front of its Gram (the other parts' work runs beside both)
-                launch_tail(v, s - 1, 1023, 0);
+                launch_full_tail(v, s - 1);
                 launch_node(v, s, 3);
                 launch_xpass(v, s, 3);
                 launch_rhs(v, s);
@@ -942,7 +954,7 @@ static int capture_linear(bnr_exec &x, int K, int p, int which, hipGraph_t *grap
             launch_chol(v, s, st);
             if (!x.lin_merge) hipLaunchKernelGGL(k_lin_gate, dim3(1), dim3(64), 0, st, pf + 1, pf + 2, s, 1, 1, x.gate_us, lf, err, dbg, p, 4);
             launch_solve(v);
-            launch_backproj(v, s, 7);
+            launch_backproj(v, s, split_sums(v) ? 3 : 7);
             if (s == K - 1) hipLaunchKernelGGL(k_advance, dim3(nbp), dim3(1), 0, st, (const bnr_dev *)v.cds, K);   // before the hand-over: the S stream's next tail finds the new base
             if (!x.lin_merge || dbg) hipLaunchKernelGGL(k_lin_set, dim3(1), dim3(64), 0, st, pf + 0, pf + 2, s, 1, 1, dbg, p, 5);
         }
@@ -1175,7 +1187,7 @@ static int run_exec(bnr_exec &x, int first_index, int count, int prog_freq, bnr_
         rc = launch_range(x, count);
         if (rc) return rc;
     }
-    if (count > 0) launch_tail(x, -1, 1023, 0);                        // scalar tail of the last sweep
+    if (count > 0) launch_full_tail(x, -1);                            // scalar tail of the last sweep
     if (x.profiling) HIPNOTE(hipEventRecord(r1, x.stream));
     // the members' event counters: one gather + one copy for the whole run call (read by the caller after the sync below)
     hipLaunchKernelGGL(k_gather_counters, dim3(x.nb), dim3(16), 0, x.stream, (const bnr_dev *)x.cds, x.status_dev);
@@ -1368,6 +1380,10 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
         x.lin = (int)value;
         return BNR_OK;
     }
+    if (!strcmp(name, "split_sums")) {
+        if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "split_sums must be -1 (default: a chain alone), 0 or 1");
+        x.split_sums = (int)value; drop_graph(x); return BNR_OK;
+    }
     if (!strcmp(name, "spw_cap")) {
         if (value < 1 || value > 4) return fail(BNR_ERR_BAD_ARG, "spw_cap must be 1..4");
         x.spw_cap = (int)value; drop_graph(x); return BNR_OK;
@@ -1501,7 +1517,7 @@ int bnr_chain_run_async(bnr_chain *c, int32_t first_index, int32_t nburn, int32_
     c->x.profiling = 0;
     hipLaunchKernelGGL(k_setbase, dim3(1), dim3(1), 0, c->x.stream, (const bnr_dev *)c->x.cds, 1);
     rc = launch_range(c->x, count);
-    if (!rc && count > 0) launch_tail(c->x, -1, 1023, 0);
+    if (!rc && count > 0) launch_full_tail(c->x, -1);
     c->x.profiling = saved;
     if (rc) return rc;
     c->pending = true;
@@ -1547,7 +1563,7 @@ int bnr_gibbs_step(bnr_chain *c, int32_t row, int64_t iter)
     int rc = hook_begin(c, row, iter, true);
     if (rc) return rc;
     launch_sweep(c->x, 0, false);
-    launch_tail(c->x, 0, 1023, 0);
+    launch_full_tail(c->x, 0);
     rc = hook_end(c, "gibbs_step");
     if (!rc) { c->carried_row = row - 1; c->iter = iter; }
     return rc;

@@ -237,6 +237,8 @@ int bnr_chain_debug_copy(bnr_chain *chain, int32_t which, double *out, int64_t c
  *   "group_xpass" -1 (default): a lockstep group whose members share the device copy of X (bnr_chain_create_like) runs ONE X pass
  *               for all members (k_xpass_group) when X has 8 MB or more per chain; 1: always; 0: one pass per member.  "group_backproj" 1: the same for the back-projection / GIG kernel
  *               (default 0: measured no faster)
+ *   "split_sums" -1 (default): a chain run alone computes the back-projection's partial sums (update_theta!, update_Lambda!) in a launch of
+ *               their own in front of the scalar tail, off the critical chain; 1: always; 0: inside the back-projection
  *   "spw_cap"   1..4 (default 4): super blocks per update workgroup of the factorization, at most (diagnostics)
  *   "linear"    (groups; opt-in, experimental) 1 / 2 / 4: every stream replays LINEAR captured graphs and the streams meet through device
  *               counters (gate / setter kernels); with 2 or 4 the members advance as that many phase-shifted parts, one part's Gram beside

@@ -1199,6 +1199,7 @@ def test_factorization_variants_are_bitwise_equal(gpu):
                            ("right, separate reduction pass, eager", {"factor_variant": 0, "fuse_reduce": 0, "graph": 0}), ("right, eager", {"factor_variant": 0, "graph": 0}),
                            ("right, X pass per chain", {"factor_variant": 0, "group_xpass": 0}),
                            ("right, X pass for the group", {"factor_variant": 0, "group_xpass": 1}),
+                           ("right, sums split off", {"factor_variant": 0, "split_sums": 1}), ("right, sums inside", {"factor_variant": 0, "split_sums": 0}),
                            ("right, back-projection for the group", {"factor_variant": 0, "group_backproj": 1}),
                            ("left", {"factor_variant": 1}), ("left, eager", {"factor_variant": 1, "graph": 0}),
                            ("two panels", {"factor_variant": 2}), ("two panels, eager", {"factor_variant": 2, "graph": 0}),
