@@ -820,7 +820,8 @@ static void launch_tail(bnr_exec &x, int s, int mask, int xg_src)
 // By default for a chain alone (its scalar branch has slack: one chain -3 us per sweep at the headline size, -7 at n = 2000); a group's scalar branch
 // is nearly critical already (8 chains: +32 us).
 // ... and not where the sums are many blocks of work (n = 500, V = 300: 1411 blocks, one chain 412 -> 478 us per sweep with the split).
-static bool split_sums(const bnr_exec &x) { return x.split_sums == 1 || (x.split_sums < 0 && x.nb == 1 && x.shape->nblk_bp <= 3 * x.ncu); }
+// ... nor where the scalar branch itself is the long pole (n_pad = 128: four panel steps; n = 70: 85.2 -> 87.2 us with the split).
+static bool split_sums(const bnr_exec &x) { return x.split_sums == 1 || (x.split_sums < 0 && x.nb == 1 && x.shape->nblk_bp <= 3 * x.ncu && x.shape->n_pad >= 256); }
 static void launch_full_tail(bnr_exec &x, int s)
 {
     if (split_sums(x)) launch_backproj(x, s, 4);
