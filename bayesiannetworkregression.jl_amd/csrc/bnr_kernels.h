@@ -1091,6 +1091,7 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const SRC chain_src, int s)
     const int nwg = gridDim.x * gridDim.y, wg = blockIdx.x * gridDim.y + blockIdx.y, np = cd.n_pad;
     for (size_t e = ((size_t)wg * 256 + threadIdx.x) * 2; e < (size_t)np * np; e += (size_t)nwg * 512) {
         int r = (int)(e % np), c = (int)(e / np);
+        if (r / BNR_NB > c / BNR_NB) continue;             // below the diagonal block Y = L^-T is never written and never read (k_solve_w, k_solve_a4)
         bnr_d2 v = {(r == c) ? 1.0 : 0.0, (r + 1 == c) ? 1.0 : 0.0};
         *(bnr_d2 *)(cd.E + (size_t)(np + r) + ld * c) = v;
     }
@@ -1382,7 +1383,7 @@ __device__ __forceinline__ void bnr_reduce_part(const bnr_dev &cd, int t, int pa
     const int np = cd.n_pad;
     for (size_t e = ((size_t)wg * 256 + threadIdx.x) * 2; e < (size_t)np * np; e += (size_t)nwg * 512) {
         const int r = (int)(e % np), c = (int)(e / np);
-        if (r < BNR_NB && c < BNR_NB) continue;
+        if ((r < BNR_NB && c < BNR_NB) || r / BNR_NB > c / BNR_NB) continue;   // (below the diagonal block Y is never written and never read)
         bnr_d2 v = {(r == c) ? 1.0 : 0.0, (r + 1 == c) ? 1.0 : 0.0};
         *(bnr_d2 *)(cd.E + (size_t)(np + r) + ld * c) = v;
     }
