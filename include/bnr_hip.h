@@ -227,7 +227,8 @@ int bnr_chain_debug_copy(bnr_chain *chain, int32_t which, double *out, int64_t c
  *   "graph_k"   sweeps per captured graph (default 8)
  *   "overlap"   1 (default): scalar branch and Gram/factorization branch of a sweep on two streams; 0: one stream
  *   "gram_variant" 0 (default): the Gram kernel is chosen per launch (k_gram8 when the launch has more than two workgroups per CU,
- *               k_gram otherwise); 8 / 16 force one of them.  Both write the same partial tiles bit for bit.
+ *               k_gram otherwise); 8 / 16 force one of them; 9: the persistent kernel k_gram8p, 10: k_gram8d (the unscaled panel by LDS-DMA) --
+ *               experiments, measured slower.  All write the same partial tiles bit for bit.
  *   "profiling" 1: record HIP events around every k_gram launch (forces eager launches), see bnr_chain_last_timing
  *   "factor_variant" -1 (default): chosen by size -- 0 below n_pad = 1024, 3 from there on; 0: right-looking factorization, one
  *               32-column panel per launch (k_gram_reduce + k_chol_step); 1: left-looking (k_chol_ll); 2: right-looking, two panels per
