@@ -84,6 +84,7 @@ _SIGS = {
     "bnr_chain_debug_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32]),
     "bnr_chain_debug_copy": (C.c_int, [C.c_void_p, C.c_int32, _dp, C.c_int64]),
     "bnr_chain_debug_time_gram": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
+    "bnr_debug_set_exp": (C.c_int, [C.c_int32, C.c_int32]),
     "bnr_host_philox": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "bnr_host_uniform2": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
     "bnr_host_normal": (C.c_double, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),

@@ -47,11 +47,18 @@ struct bnr_exec {
     int pipeline = -1;                                  // -1: chosen by size / availability; 0: the factorization follows the Gram; 1: beside it
     int gate_us = 3000;                                 // how long a gate of the factorization polls for the Gram's progress
     unsigned *gctl = nullptr;                           // k_gram8p: queue heads and tickets
+#ifdef BNR_EXPERIMENTS
     bnr_gramq gq{};                                     // k_gram8p: the per-XCD task lists inside gmapc (set by the owner from its inputs)
+    bnr_qent *qlist = nullptr;                          // k_gram8q: the per-XCD lists of (task, chain) entries of THIS exec (build_qlist), qq = their offsets
+    bnr_gramq qq{};
+    int qW = 0, q_for_mask = -1;                        // seats (CUs) of an XCD the resident Gram uses; the resv_mask the lists were built for
+#endif
     const unsigned *resv = nullptr;                     // reserved compute units (device table shared per device), nullptr: none
     std::vector<hipEvent_t> fj;                         // fork/join events
     size_t fj_next = 0;
     int overlap = 1;
+    int resv_mask = 0x80;                               // k_gram8q: cu ids (inside a shader engine) it keeps off -- 0x80 = cu id 7 of every SE = 32 CUs
+    int crit_origin = 0;                                // 1: the critical chain (Gram, factorization, solve, back-projection) stays on the capture origin's queue and the scalar branch is the forked one; 2: the same with an empty kernel captured as the first fork
     int gram_variant = 0;                               // 0: chosen per launch; 8 / 16: k_gram8 / k_gram forced (tests, experiments)
     int fuse_reduce = -1;                               // -1 / 1: launch 0 of the one-panel factorization also sums the Gram's K-split partials (no k_gram_reduce launch); 0: separate pass
     int group_backproj = 0;                             // 1: the same for the back-projection / GIG kernel (opt-in: bitwise equal, measured no faster -- the block is bound by the latency of the draws' arithmetic)
@@ -104,7 +111,8 @@ struct bnr_chain {
     int *pbase_dev = nullptr;
     size_t trace_bytes = 0;
     struct bnr_group *group = nullptr;   // lockstep group this chain belongs to (at most one)
-    const unsigned char *x8_kept = nullptr;   // the byte image of X while option "byte_x" is 0
+    const unsigned char *x8_kept = nullptr;   // the byte image of X (also while option "byte_x" is 0); nullptr: the input had none
+    long long cap_seen = 0;      // sampler-cap events already reported (the device counter is cumulative: a capped draw is reported by the call it happened in, once)
 };
 
 struct bnr_group {
@@ -142,8 +150,11 @@ static int ensure_lds_attributes(int device)
     const int big = 124 * 1024;
     const void *fns[] = {(const void *)&k_tail<bnr_one>, (const void *)&k_tail<bnr_many>, (const void *)&k_backproj<bnr_one>,
                          (const void *)&k_backproj<bnr_many>, (const void *)&k_solve_a4<bnr_one>, (const void *)&k_solve_a4<bnr_many>,
+#ifdef BNR_EXPERIMENTS
                          (const void *)&k_chol_ll<bnr_one>, (const void *)&k_chol_ll<bnr_many>,
-                         (const void *)&k_gram_gate<bnr_one>, (const void *)&k_gram_gate<bnr_many>, (const void *)&k_backproj_group, (const void *)&k_xpass_group};
+                         (const void *)&k_gram_gate<bnr_one>, (const void *)&k_gram_gate<bnr_many>, (const void *)&k_backproj_group,
+#endif
+                         (const void *)&k_xpass_group};
     for (const void *f : fns) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     done[device] = 1;
     return BNR_OK;
@@ -336,6 +347,7 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     TRY(exec_init(c->x, device, 1, &c->d));
     if (donor) {
         c->in = donor->in;
+        c->x8_kept = donor->x8_kept;                     // the image belongs to the shared inputs: a chain made from a donor with byte_x = 0 can switch it on again
         d.X = donor->d.X; d.X8 = donor->d.X8; d.y = donor->d.y; d.ek = donor->d.ek; d.el = donor->d.el; d.gmap = donor->d.gmap; d.gmapc = donor->d.gmapc;
     } else {
         c->in = std::make_shared<bnr_inputs>();
@@ -373,9 +385,15 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
             int not_bytes = 0;
             if (hipMemcpy(&not_bytes, nb, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "copy failed"); }
             const char *off = getenv("BNR_NO_BYTE_X");
-            if (not_bytes || (off && atoi(off))) X8 = nullptr;         // (the buffer stays with the inputs and is freed with them)
+            if (not_bytes || (off && atoi(off))) {                     // no byte image after all: give its memory back (an eighth of X: 22 MB at config 5)
+                auto it = std::find(c->in->bufs.begin(), c->in->bufs.end(), (void *)X8);
+                if (it != c->in->bufs.end()) c->in->bufs.erase(it);
+                (void)hipFree(X8);
+                X8 = nullptr;
+            }
         }
         d.X8 = X8;
+        c->x8_kept = X8;
         {
             // XCD-aware task map of k_gram (tasks = lower tiles x K slices): workgroup i runs on XCD i % 8; give it a K
             // slice ks with ks % 8 == i % 8 while there are any, so that a slice of X is read through one XCD's L2
@@ -426,7 +444,9 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
         d.X = Xd; d.y = yd; d.ek = ek; d.el = el; d.gmap = gm; d.gmapc = gmc;
         for (int x = 0; x < 9; ++x) c->in->gq_off[x] = gq_off[x];
     }
+#ifdef BNR_EXPERIMENTS
     for (int x = 0; x < 9; ++x) c->x.gq.qoff[x] = c->in->gq_off[x];
+#endif
     TRY(alloc_trace(c, tot_save, &d.trace));
     TRY(dev_alloc(c, &d.Wbuf, d.q_pad));
     TRY(dev_alloc(c, &d.sz, d.q_pad));
@@ -457,6 +477,7 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     if (hipHostMalloc((void **)&c->counters_host, sizeof(long long) * 16) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipHostMalloc failed"); }
     d.plan = c->plan_dev;
     TRY(sync_dev(c));
+    TRY(check_launch("chain_build"));                    // the index-map / task-map copies above only NOTE a failure: report it here, not in somebody's later call
 #undef TRY
     *out = c;
     return BNR_OK;
@@ -482,49 +503,6 @@ int bnr_chain_create_like(const bnr_chain *donor, uint64_t seed, int32_t chain_i
     return chain_build(donor, a.n, a.V, a.R, x_source(), nullptr, &h, seed, chain_id, donor->device, tot_save, out);
 }
 
-// Compute units the persistent Gram keeps off (k_gram8p): the `per_se` highest cu ids of EVERY shader engine -- the dispatcher walks
-// the shader engines round-robin and a workgroup whose SE has no room blocks every workgroup behind it, so all SEs must offer
-// the same room.  Which cu ids exist differs per SE (8 of 9 are active): measured once per device by k_cu_census.  Returns a
-// device table [XCD * 4 + SE] -> bit mask of reserved cu ids, or nullptr when the census does not look like 8 XCDs x 4 SEs x 8 CUs.
-static const unsigned *reserved_cus(int device, int per_se)
-{
-    static std::mutex mu;
-    static std::vector<unsigned *> tab;
-    static std::vector<char> done;
-    std::lock_guard<std::mutex> lock(mu);
-    if ((int)done.size() <= device) { done.resize(device + 1, 0); tab.resize(device + 1, nullptr); }
-    if (done[device]) return tab[device];
-    done[device] = 1;
-    const char *off = getenv("BNR_NO_RESERVED_CUS");
-    if (off && atoi(off)) return nullptr;
-    unsigned *d = nullptr, h[33];
-    if (hipMalloc((void **)&d, sizeof h) != hipSuccess) return nullptr;
-    bool ok = hipMemset(d, 0, sizeof h) == hipSuccess;
-    if (ok) {
-        hipLaunchKernelGGL(k_cu_census, dim3(4096), dim3(1024), 0, nullptr, d, 2000);     // 20 us each, 1024 threads: one or two per CU at a time
-        ok = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
-    }
-    int total = 0;
-    for (int i = 0; ok && i < 32; ++i) {
-        const int n = __builtin_popcount(h[i]);
-        total += n;
-        if (n < 2 * per_se + 2) ok = false;                                              // an SE this small: do not reserve anything
-    }
-    hipDeviceProp_t prop;
-    if (ok && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount != total) ok = false;
-    if (ok) {
-        for (int i = 0; i < 32; ++i) {
-            unsigned m = 0, left = h[i];
-            for (int k = 0; k < per_se; ++k) { const unsigned top = 31u - (unsigned)__builtin_clz(left); m |= 1u << top; left &= ~(1u << top); }
-            h[i] = m;
-        }
-        ok = hipMemcpy(d, h, 32 * sizeof(unsigned), hipMemcpyHostToDevice) == hipSuccess;
-    }
-    if (!ok) { (void)hipFree(d); return nullptr; }
-    tab[device] = d;
-    return d;
-}
-
 static void drop_graph(bnr_exec &x)
 {
     for (auto &r : x.ladder) { if (r.gexec) (void)hipGraphExecDestroy(r.gexec); if (r.graph) (void)hipGraphDestroy(r.graph); }
@@ -541,8 +519,10 @@ static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape)
     }
     HIPCHK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&x.stream2, hipStreamNonBlocking));
-    HIPCHK(hipMalloc((void **)&x.gctl, 64));
-    HIPCHK(hipMemset(x.gctl, 0, 64));
+#ifdef BNR_EXPERIMENTS
+    HIPCHK(hipMalloc((void **)&x.gctl, sizeof(unsigned) * 8 * BNR_GQ_WORDS));
+    HIPCHK(hipMemset(x.gctl, 0, sizeof(unsigned) * 8 * BNR_GQ_WORDS));
+#endif
     HIPCHK(hipMalloc((void **)&x.cds, sizeof(bnr_dev) * nb));
     HIPCHK(hipHostMalloc((void **)&x.cds_pin, sizeof(bnr_dev) * nb));
     HIPCHK(hipMalloc((void **)&x.status_dev, sizeof(long long) * 16 * nb));
@@ -557,6 +537,9 @@ static void exec_free(bnr_exec &x)
     if (x.stream4) { (void)hipStreamSynchronize(x.stream4); (void)hipStreamDestroy(x.stream4); }
     for (hipStream_t st : x.lstreams) { (void)hipStreamSynchronize(st); }
     if (x.gctl) (void)hipFree(x.gctl);
+#ifdef BNR_EXPERIMENTS
+    if (x.qlist) (void)hipFree(x.qlist);
+#endif
     drop_graph(x);
     for (hipStream_t st : x.lstreams) (void)hipStreamDestroy(st);
     x.lstreams.clear();
@@ -588,10 +571,10 @@ int bnr_group_destroy(bnr_group *g);
 int bnr_chain_destroy(bnr_chain *c)
 {
     if (!c) return BNR_OK;
-    HIPNOTE(hipSetDevice(c->device));
+    (void)hipSetDevice(c->device);                       // (best effort: a destructor has nobody to report to, and must not leave an error noted for the thread's next call)
     if (c->group) {                                      // a group cannot run without a member: dissolve it (the handle stays valid)
         bnr_group *g = c->group;
-        HIPNOTE(hipStreamSynchronize(g->x.stream));
+        (void)hipStreamSynchronize(g->x.stream);
         for (bnr_chain *m : g->m) m->group = nullptr;
         g->m.clear();
     }
@@ -620,7 +603,7 @@ static int ensure_plan(bnr_chain *c, int count)
     c->plan_dev = nd; c->plan_pin = np; c->plan_cap = cap;
     c->d.plan = nd;
     drop_graph(c->x);                       // one chain: the struct is a by-value kernel argument baked into the captured graph
-    if (c->group) drop_graph(c->group->x);  // ... also into the graphs of a ONE-member group (bnr_one there too)
+    if (c->group && c->group->x.nb == 1) drop_graph(c->group->x);  // ... also into the graphs of a ONE-member group (bnr_one there too); larger groups read the device array
     return sync_dev(c);
 }
 // st: the stream the sweeps that read this plan are issued on (the chain's own, or its group's: no cross-stream hand-over)
@@ -677,14 +660,18 @@ static void launch_xpass(bnr_exec &x, int s, int which)
 // run beside the Gram).  Same tables bit for bit.
 static bool left_looking(const bnr_exec &x)
 {
+#ifdef BNR_EXPERIMENTS
     return x.factor_variant == 1;                        // opt-in: measured slower than right-looking in every schedule tried (notes round 3, B)
+#else
+    (void)x; return false;
+#endif
 }
 // The sweep's schedule: pipelined (option "pipeline" = 1) = the factorization runs BESIDE the Gram (k_gram8p keeps off the reserved
 // CUs, k_chol_ll's gates follow its progress column by column); otherwise it follows the Gram on the same stream.
 static bool pipelined(const bnr_exec &x)
 {
     if (!left_looking(x) || !x.overlap || x.shape->gram_kg != 2) return false;
-    return x.pipeline == 1 && x.resv;                              // opt-in (notes round 3, B)
+    return x.pipeline == 1;                                        // opt-in, experiments build only (notes round 3 B, round 4 B)
 }
 // two panels per launch with the K = 128 trailing update (variant 3) where the trailing update is bandwidth-bound: n_pad >= 1024
 // (n = 2000 one chain 424 -> 448 it/s, n = 1000 eight chains 5.49 -> 5.88 k it/s; at n = 500 it is a draw and the one-panel launches stay)
@@ -712,8 +699,22 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
         HIPNOTE(hipEventRecord(e0, st));
     }
     const dim3 ggrid(round_up(ntl * d.ksplit, 8) * x.nb);
-    if (x.gram_variant == 9 || (x.gram_variant == 0 && pipelined(x))) {
-        const unsigned *resv = pipelined(x) ? x.resv : nullptr;
+#ifdef BNR_EXPERIMENTS
+    if (x.gram_variant == 13 || (x.gram_variant == 0 && pipelined(x))) {
+        // resident Gram that keeps off the reserved CUs; its queue heads are zeroed here, on the issuing stream (a memset node of the captured graph)
+        hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(1024), 0, st, x.gctl, 8 * BNR_GQ_WORDS);
+        const dim3 qgrid(3 * x.ncu);
+        const unsigned mask = (unsigned)x.resv_mask;
+        if (!x.qlist) { g_noted = hipErrorInvalidValue; g_noted_what = "k_gram8q without its work lists (build_qlist)"; return; }
+        if (pipelined(x)) {
+            if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8q<bnr_one, true>), qgrid, dim3(512), 0, st, bnr_one{d}, s, (const bnr_qent *)x.qlist, x.qq, mask, x.gctl, x.qW);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8q<bnr_many, true>), qgrid, dim3(512), 0, st, bnr_many{x.cds}, s, (const bnr_qent *)x.qlist, x.qq, mask, x.gctl, x.qW);
+        } else {
+            if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8q<bnr_one, false>), qgrid, dim3(512), 0, st, bnr_one{d}, s, (const bnr_qent *)x.qlist, x.qq, mask, x.gctl, x.qW);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8q<bnr_many, false>), qgrid, dim3(512), 0, st, bnr_many{x.cds}, s, (const bnr_qent *)x.qlist, x.qq, mask, x.gctl, x.qW);
+        }
+    } else if (x.gram_variant == 9) {
+        const unsigned *resv = nullptr;
         const dim3 pgrid(BNR_G8P_WPC * x.ncu);
         if (resv) {
             if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_one, true>), pgrid, dim3(512), 0, st, bnr_one{d}, s, 1, x.gq, resv, x.gctl);
@@ -722,7 +723,9 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
             if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_one, false>), pgrid, dim3(512), 0, st, bnr_one{d}, s, 1, x.gq, resv, x.gctl);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_many, false>), pgrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb, x.gq, resv, x.gctl);
         }
-    } else if (d.gram_kg == 4) {
+    } else
+#endif
+    if (d.gram_kg == 4) {
         if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), ggrid, dim3(1024), 0, st, bnr_one{d}, s, 1);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_many, 4>), ggrid, dim3(1024), 0, st, bnr_many{x.cds}, s, x.nb);
     } else {
@@ -732,10 +735,25 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
         // workgroups than two per CU.  A launch that fits in one round (one chain: 252 workgroups at the headline size) never reaches
         // that occupancy and is better off with k_gram's 16-column batches = half the barriers (33.5 vs 36.0 us; n=500, V=300: 228 vs 237).
         const bool wide = x.gram_variant ? x.gram_variant == 16 : ((long)x.nb * ntl * d.ksplit <= 2L * x.ncu);
-        if (x.gram_variant == 10) {                        // experiment: the unscaled panel by LDS-DMA
+#ifdef BNR_EXPERIMENTS
+        if (x.gram_variant == 11 || x.gram_variant == 12 || x.gram_variant == 14) {   // one resident round, static task loop (12: with the priority rotation; 14: in queue order)
+            const dim3 sgrid(3 * x.ncu);
+            if (x.gram_variant == 11) {
+                if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_one, 0>), sgrid, dim3(512), 0, st, bnr_one{d}, s, 1, x.gq);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_many, 0>), sgrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb, x.gq);
+            } else if (x.gram_variant == 14) {
+                if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_one, 2>), sgrid, dim3(512), 0, st, bnr_one{d}, s, 1, x.gq);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_many, 2>), sgrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb, x.gq);
+            } else {
+                if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_one, 1>), sgrid, dim3(512), 0, st, bnr_one{d}, s, 1, x.gq);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_many, 1>), sgrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb, x.gq);
+            }
+        } else if (x.gram_variant == 10) {                        // experiment: the unscaled panel by LDS-DMA
             if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8d<bnr_one>), ggrid, dim3(512), 0, st, bnr_one{d}, s, 1);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8d<bnr_many>), ggrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb);
-        } else if (!wide) {
+        } else
+#endif
+        if (!wide) {
             if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8<bnr_one>), ggrid, dim3(512), 0, st, bnr_one{d}, s, 1);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8<bnr_many>), ggrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb);
         } else {
@@ -746,6 +764,84 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
     if (timed) HIPNOTE(hipEventRecord(e1, st));
     if (!left_looking(x) && !reduce_in_chol(x)) BNR_LAUNCH(k_gram_reduce, dim3(ntl, 8, x.nb), dim3(256), 0, st, x, s);
 }
+#ifdef BNR_EXPERIMENTS
+// k_gram8q's work lists (see the kernel): for every XCD a list of (tile | K slice << 16, chain) entries in tile-COLUMN order, all of
+// (nearly) the same length.  XCD x gets the K slices ks = x mod 8 (one slice of X per L2); XCDs that would hold more than an eighth of
+// the entries give whole tasks (all chains of a tile and slice: they share its panels of X), evenly spaced over the columns, to those that
+// hold less.  Built once per exec and reservation mask, outside any stream capture.
+static int build_qlist(bnr_exec &x)
+{
+    if (x.qlist && x.q_for_mask == x.resv_mask) return BNR_OK;
+    const bnr_dev &d = *x.shape;
+    const int nb = x.nb, ntile = d.ntile;
+    struct unit { int task, c0, c1, col; };
+    std::vector<std::vector<unit>> bucket(8);
+    for (int tc = 0; tc < ntile; ++tc)
+        for (int ti = tc; ti < ntile; ++ti)
+            for (int ks = 0; ks < d.ksplit; ++ks) bucket[ks % 8].push_back(unit{(ti * (ti + 1) / 2 + tc) | (ks << 16), 0, nb, tc});
+    const long total = (long)ntile * (ntile + 1) / 2 * d.ksplit * nb;
+    const long T = (total + 7) / 8;
+    auto entries = [](const std::vector<unit> &v) { long n = 0; for (const unit &u : v) n += u.c1 - u.c0; return n; };
+    std::vector<unit> pool;
+    for (int b = 0; b < 8; ++b) {
+        long excess = entries(bucket[b]) - T;
+        if (excess <= 0) continue;
+        const int ngive = (int)((excess + nb - 1) / nb), ntask = (int)bucket[b].size();
+        std::vector<char> give(ntask, 0);
+        for (int k = 0; k < ngive; ++k) give[std::min(ntask - 1, (int)(((2L * k + 1) * ntask) / (2L * ngive)))] = 1;
+        std::vector<unit> keep;
+        for (int i = 0; i < ntask; ++i) {
+            unit u = bucket[b][i];
+            if (give[i] && excess > 0) {
+                const int g = (int)std::min<long>(excess, nb);          // the last one may be a part of a task: its first g chains go, the others stay
+                pool.push_back(unit{u.task, 0, g, u.col});
+                if (g < nb) keep.push_back(unit{u.task, g, nb, u.col});
+                excess -= g;
+            } else keep.push_back(u);
+        }
+        bucket[b] = keep;
+    }
+    // deal the pool to the lists that are short, a unit at a time (split where it does not fit)
+    size_t pi = 0;
+    while (pi < pool.size()) {
+        bool moved = false;
+        for (int b = 0; b < 8 && pi < pool.size(); ++b) {
+            long need = T - entries(bucket[b]);
+            if (need <= 0) continue;
+            unit &u = pool[pi];
+            const int g = (int)std::min<long>(need, u.c1 - u.c0);
+            bucket[b].push_back(unit{u.task, u.c0, u.c0 + g, u.col});
+            u.c0 += g;
+            if (u.c0 >= u.c1) ++pi;
+            moved = true;
+        }
+        if (!moved) return fail(BNR_ERR_BAD_ARG, "internal: the Gram work lists do not balance");
+    }
+    std::vector<bnr_qent> flat;
+    for (int b = 0; b < 8; ++b) {
+        std::stable_sort(bucket[b].begin(), bucket[b].end(), [](const unit &a, const unit &c) { return a.col < c.col; });
+        x.qq.qoff[b] = (int)flat.size();
+        for (const unit &u : bucket[b]) for (int c = u.c0; c < u.c1; ++c) flat.push_back(bnr_qent{u.task, c});
+    }
+    x.qq.qoff[8] = (int)flat.size();
+    if ((long)flat.size() != total) return fail(BNR_ERR_BAD_ARG, "internal: the Gram work lists lost entries");
+    HIPCHK(hipSetDevice(x.device));
+    if (x.qlist) { HIPCHK(hipStreamSynchronize(x.stream)); (void)hipFree(x.qlist); x.qlist = nullptr; }
+    HIPCHK(hipMalloc((void **)&x.qlist, sizeof(bnr_qent) * std::max<size_t>(flat.size(), 1)));
+    HIPCHK(hipMemcpy(x.qlist, flat.data(), sizeof(bnr_qent) * flat.size(), hipMemcpyHostToDevice));
+    x.qW = std::max(1, std::min(BNR_GQ_WORDS - 65, x.ncu / 8 - 4 * __builtin_popcount((unsigned)x.resv_mask)));   // seats = CUs of an XCD the Gram may use
+    x.q_for_mask = x.resv_mask;
+    return BNR_OK;
+}
+#else
+static int build_qlist(bnr_exec &) { return BNR_OK; }
+#endif
+static bool wants_qlist(const bnr_exec &x);
+#ifdef BNR_EXPERIMENTS
+static bool wants_qlist(const bnr_exec &x) { return x.gram_variant == 13 || (x.gram_variant == 0 && pipelined(x)); }
+#else
+static bool wants_qlist(const bnr_exec &) { return false; }
+#endif
 static void launch_rhs(bnr_exec &x, int s) { BNR_LAUNCH(k_rhs, dim3(x.shape->n_pad / 64, 1, x.nb), dim3(256), 0, x.stream, x, s); }
 static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
 {
@@ -761,12 +857,16 @@ static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
         }
         return;
     }
+#ifdef BNR_EXPERIMENTS
     if (left_looking(x)) {
         const int nA = (nbk + 3) / 4, nB = nbk - 1;
         for (int p = 0; p < nbk; ++p)
             BNR_LAUNCH(k_chol_ll, dim3(x.nb, nA + (p + 1 < nbk ? nB : 0)), dim3(256), BNR_LL_LDS, st, x, p, s, nA, spin_us);
         return;
     }
+#else
+    (void)spin_us;
+#endif
     // update workgroups: one 32 x 32 block each while panels + updates of all members fit the chip in one round (two 256-thread
     // workgroups per CU); otherwise (large n, groups) 64 x 64 super blocks
     const int ncu = x.ncu, fuse0 = reduce_in_chol(x) ? 1 : 0;
@@ -800,6 +900,7 @@ static void launch_solve(bnr_exec &x)
 static void launch_backproj(bnr_exec &x, int s, int flags)
 {
     size_t lds = std::max<size_t>(x.shape->n_pad + 64, (size_t)(3 * x.shape->R + 1) * 33) * sizeof(double);
+#ifdef BNR_EXPERIMENTS
     if (flags == 7 && x.group_backproj == 1 && group_shares_x(x)) {
         // one workgroup per block of 32 edges for BNR_BPG_CT members: X read once per tile of members, four speculative attempts per draw
         const int R = x.shape->R, SA = std::max(std::max(x.shape->n_pad, (3 * R + 1) * 33), 32 * 22);
@@ -809,6 +910,7 @@ static void launch_backproj(bnr_exec &x, int s, int flags)
             return;
         }
     }
+#endif
     const int nslot = (x.nb * x.shape->nblk_bp <= 2 * x.ncu) ? 8 : 2;    // speculative GIG attempts per edge and round
     BNR_LAUNCH(k_backproj, dim3(round_up(x.shape->nblk_bp, 8) * x.nb), dim3(256), lds, x.stream, x, s, flags, x.nb, nslot);
 }
@@ -853,6 +955,7 @@ static void launch_sweep(bnr_exec &x, int s, bool prev_tail)
     hipStream_t sb = overlap ? x.stream2 : x.stream;
     const bool pipe = pipelined(x);
     hipEvent_t ej[3] = {nullptr, nullptr, nullptr};
+#ifdef BNR_EXPERIMENTS
     if (pipe) {
         // branch B: the Gram (persistent, off the reserved CUs); branch C: the factorization, gated on the Gram's progress; and in front
         // of both a branch of one empty kernel: hipGraph runs the FIRST-captured forked branch to its end before it starts any other
@@ -869,7 +972,38 @@ static void launch_sweep(bnr_exec &x, int s, bool prev_tail)
         BNR_LAUNCH(k_gram_gate, dim3(x.nb), dim3(64), 72 * 1024, x.stream3, x, 0, x.gate_us);
         launch_chol(x, s, x.stream3, x.gate_us);
         HIPNOTE(hipEventRecord(ej[2] = next_event(x), x.stream3));
-    } else if (overlap) {
+    } else if (overlap && x.crit_origin) {
+        // the scalar branch is the forked one: the critical chain never changes queue (a kernel whose predecessor sits on another queue
+        // starts ~5 us late, profiles/round3_timeline_default.txt: chol step 15 -> solve, back-projection -> Gram)
+        hipEvent_t ef = next_event(x);
+        HIPNOTE(hipEventRecord(ef, x.stream));
+        hipEvent_t e4 = nullptr;
+        if (x.crit_origin == 2 && x.stream4) {
+            HIPNOTE(hipStreamWaitEvent(x.stream4, ef, 0));
+            hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, x.stream4);
+            HIPNOTE(hipEventRecord(e4 = next_event(x), x.stream4));
+        }
+        HIPNOTE(hipStreamWaitEvent(x.stream2, ef, 0));
+        std::swap(x.stream, x.stream2);                    // the launch helpers of the scalar branch issue on x.stream
+        if (prev_tail) launch_full_tail(x, s - 1);
+        launch_node(x, s, 3);
+        launch_xpass(x, s, 3);
+        launch_rhs(x, s);
+        hipEvent_t es = next_event(x);
+        HIPNOTE(hipEventRecord(es, x.stream));
+        std::swap(x.stream, x.stream2);
+        launch_gram(x, s, x.stream, timed);
+        launch_chol(x, s, x.stream);
+        HIPNOTE(hipStreamWaitEvent(x.stream, es, 0));
+        if (e4) HIPNOTE(hipStreamWaitEvent(x.stream, e4, 0));
+        launch_solve(x);
+        launch_backproj(x, s, split_sums(x) ? 3 : 7);
+        return;
+    } else
+#else
+    (void)pipe;
+#endif
+    if (overlap) {
         hipEvent_t ef = next_event(x);
         HIPNOTE(hipEventRecord(ef, x.stream));
         HIPNOTE(hipStreamWaitEvent(x.stream2, ef, 0));
@@ -900,6 +1034,7 @@ static int collect_gram_times(bnr_exec &x, int nsweeps)
     return BNR_OK;
 }
 
+#ifdef BNR_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------- linear schedule
 // The members of a group as `lin` parts (1, 2 or 4), every part with two streams -- C: ring gate, Gram, factorization, gate, solve,
 // back-projection; S: gate, the scalar branch -- and every stream replaying LINEAR graphs.  The parts are phase-shifted by a ring of
@@ -997,6 +1132,7 @@ static int linear_range(bnr_exec &x, int count)
     x.n_replayed += count;
     return BNR_OK;
 }
+#endif
 // Capture K sweeps (+ the plan-base advance) into a graph and instantiate it.  The kernels find their plan entry through
 // pbase at run time, so a captured graph serves every later batch.
 static int capture_sweeps(bnr_exec &x, int K, hipGraph_t *graph, hipGraphExec_t *gexec)
@@ -1016,6 +1152,7 @@ static int capture_sweeps(bnr_exec &x, int K, hipGraph_t *graph, hipGraphExec_t 
 // Built here, outside anybody's timed region.
 static int exec_prepare(bnr_exec &x)
 {
+    if (wants_qlist(x)) { int rq = build_qlist(x); if (rq) return rq; }
     if (!x.use_graph || x.profiling || x.graph_k <= 0 || !x.ladder.empty()) return BNR_OK;
     for (int k = x.graph_k; k >= 1; k /= 2) {
         bnr_exec::rung r{k, nullptr, nullptr};
@@ -1029,6 +1166,8 @@ static int exec_prepare(bnr_exec &x)
 static int launch_range(bnr_exec &x, int count)
 {
     int done = 0;
+    if (wants_qlist(x)) { int rq = build_qlist(x); if (rq) return rq; }
+#ifdef BNR_EXPERIMENTS
     if (linear_mode(x) && x.graph_k > 0) {
         // the lin streams start behind everything enqueued on x.stream so far and x.stream continues behind them
         hipEvent_t e0 = nullptr;
@@ -1041,6 +1180,7 @@ static int launch_range(bnr_exec &x, int count)
         (void)hipEventDestroy(e0);
         return rc;
     }
+#endif
     if (x.use_graph && !x.profiling && x.graph_k > 0) {     // profiling records HIP events around k_gram: eager launches
         int rc = exec_prepare(x);
         if (rc) return rc;
@@ -1082,8 +1222,10 @@ static int refresh_carried(bnr_chain *c, int r)
     return check_launch("refresh");
 }
 
-// status of a chain from its 16 event counters (host copy)
-static int status_of(const long long *cnt)
+// status of a chain from its 16 event counters (host copy).  Hard failures (stream ordering, Cholesky) are sticky: the table is not the
+// sampler's from there on.  The attempt cap of a rejection sampler is reported by the call in which it happened and only by that one
+// (cap_seen): the rows were written with the samplers' fall-backs, the table stays usable, later calls are not failed for it.
+static int status_of(const long long *cnt, long long *cap_seen)
 {
     if (cnt[8] > 0) return fail(BNR_ERR_HIP, "stream ordering violated: the factorization started before the Gram branch finished");
     if (cnt[3] > 0) {
@@ -1091,14 +1233,16 @@ static int status_of(const long long *cnt)
         snprintf(buf, sizeof buf, "Cholesky failed after the jitter ladder (node %lld, Psi %lld, M %lld, G+I %lld)", cnt[4], cnt[5], cnt[6], cnt[7]);
         return fail(BNR_ERR_CHOLESKY, buf);
     }
-    if (cnt[2] > 0) return fail(BNR_ERR_SAMPLER_CAP, "a rejection sampler stopped at its attempt cap (" + std::to_string(cnt[2]) + " draws): the values written are the samplers' fall-backs");
+    const long long before = cap_seen ? *cap_seen : 0;
+    if (cap_seen) *cap_seen = cnt[2];
+    if (cnt[2] > before) return fail(BNR_ERR_SAMPLER_CAP, "a rejection sampler stopped at its attempt cap (" + std::to_string(cnt[2] - before) + " draws in this call, " + std::to_string(cnt[2]) + " since the chain was created): the values written are the samplers' fall-backs; the table stays valid and later calls are not failed for it");
     return BNR_OK;
 }
 static int fetch_status(bnr_chain *c)
 {
     HIPCHK(hipMemcpyAsync(c->counters_host, c->d.counters, sizeof(long long) * 16, hipMemcpyDeviceToHost, c->x.stream));
     HIPCHK(hipStreamSynchronize(c->x.stream));
-    return status_of(c->counters_host);
+    return status_of(c->counters_host, &c->cap_seen);
 }
 
 int bnr_chain_init_prior(bnr_chain *c)
@@ -1220,7 +1364,7 @@ int bnr_chain_run(bnr_chain *c, int32_t first_index, int32_t nburn, int32_t tota
     if (rc) return rc;
     c->carried_row = c->plan_pin[count].row;
     if (next_row) *next_row = c->next_row;
-    return status_of(c->x.status_pin);
+    return status_of(c->x.status_pin, &c->cap_seen);
 }
 
 // ------------------------------------------------------------------------------------------ lockstep groups
@@ -1247,7 +1391,9 @@ int bnr_group_create(bnr_chain *const *chains, int32_t nchains, bnr_group **out)
     g->m.assign(chains, chains + nchains);
     int rc = exec_init(g->x, chains[0]->device, nchains, &chains[0]->d);
     if (rc) { exec_free(g->x); delete g; return rc; }
+#ifdef BNR_EXPERIMENTS
     g->x.gq = chains[0]->x.gq;
+#endif
     for (size_t i = 0; i < g->m.size(); ++i) g->x.cds_pin[i] = g->m[i]->d;   // host copy from the start: launch choices made at capture time (group_shares_x) read it
     for (bnr_chain *c : g->m) c->group = g;
     *out = g;
@@ -1257,7 +1403,7 @@ int bnr_group_create(bnr_chain *const *chains, int32_t nchains, bnr_group **out)
 int bnr_group_destroy(bnr_group *g)
 {
     if (!g) return BNR_OK;
-    HIPNOTE(hipSetDevice(g->x.device));
+    (void)hipSetDevice(g->x.device);
     for (bnr_chain *c : g->m) c->group = nullptr;
     exec_free(g->x);
     delete g;
@@ -1324,13 +1470,14 @@ int bnr_group_run(bnr_group *g, int32_t first_index, int32_t nburn, int32_t tota
     if (rc) return rc;
     for (size_t i = 0; i < g->m.size(); ++i) {
         g->m[i]->carried_row = g->m[i]->plan_pin[count].row;
-        int r2 = status_of(g->x.status_pin + 16 * i);
+        int r2 = status_of(g->x.status_pin + 16 * i, &g->m[i]->cap_seen);
         if (r2 && !rc) rc = r2;
     }
     if (next_row) *next_row = g->m[0]->next_row;
     return rc;
 }
 
+#ifdef BNR_EXPERIMENTS
 // the extra streams of the opt-in pipelined schedules are created when somebody asks for one (the default path creates nothing new)
 static int ensure_pipeline_streams(bnr_exec &x, int mode)
 {
@@ -1343,44 +1490,43 @@ static int ensure_pipeline_streams(bnr_exec &x, int mode)
         HIPCHK(hipStreamCreateWithPriority(&x.stream3, hipStreamNonBlocking, hi));
     }
     if (!x.stream4) HIPCHK(hipStreamCreateWithFlags(&x.stream4, hipStreamNonBlocking));
-    if (mode == 1 && !x.resv) x.resv = reserved_cus(x.device, 1);          // the census of compute units runs once per device, only for those who ask
+    (void)mode;                                                            // (the resident Gram k_gram8q keeps off cu ids by mask: no census of compute units)
     return BNR_OK;
+}
+#endif
+// Options that exist only in a library built with -DBNR_EXPERIMENTS (csrc/bnr_experiments.h): the shipped library refuses them by name, so that
+// nothing a user can set starts a kernel that polls device memory
+static bool experimental_option(const char *name)
+{
+    for (const char *e : {"resv_mask", "crit_origin", "group_backproj", "linear", "linear_merge", "linear_debug", "pipeline", "gate_us"})
+        if (!strcmp(name, e)) return true;
+    return false;
 }
 static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
 {
     if (!strcmp(name, "graph")) { x.use_graph = (int)value; return BNR_OK; }
     if (!strcmp(name, "overlap")) { x.overlap = (int)value; drop_graph(x); return BNR_OK; }
+#ifndef BNR_EXPERIMENTS
+    if (experimental_option(name)) return fail(BNR_ERR_BAD_ARG, std::string("option ") + name + " belongs to the measured experiments: build the library with -DBNR_EXPERIMENTS (tools/r4_build_variants.sh)");
+#endif
     if (!strcmp(name, "gram_variant")) {
-        if (value != 0 && value != 8 && value != 9 && value != 10 && value != 16) return fail(BNR_ERR_BAD_ARG, "gram_variant must be 0 (auto), 8, 9 (persistent), 10 (LDS-DMA experiment) or 16");
+#ifdef BNR_EXPERIMENTS
+        const bool ok = value == 0 || value == 8 || value == 16 || (value >= 9 && value <= 14);
+        const char *msg = "gram_variant must be 0 (auto), 8, 16, or an experiment: 9 (persistent, two per CU), 10 (LDS-DMA), 11 / 12 / 14 (one resident round, static task loop), 13 (resident, per-CU work lists, reserved CUs)";
+#else
+        const bool ok = value == 0 || value == 8 || value == 16;
+        const char *msg = "gram_variant must be 0 (auto), 8 or 16 (the experimental kernels 9..14 need a library built with -DBNR_EXPERIMENTS)";
+#endif
+        if (!ok) return fail(BNR_ERR_BAD_ARG, msg);
         x.gram_variant = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "fuse_reduce")) {
         if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "fuse_reduce must be -1 (default: on), 0 or 1");
         x.fuse_reduce = (int)value; drop_graph(x); return BNR_OK;
     }
-    if (!strcmp(name, "group_backproj")) {
-        if (value < 0 || value > 1) return fail(BNR_ERR_BAD_ARG, "group_backproj must be 0 (default) or 1");
-        x.group_backproj = (int)value; drop_graph(x); return BNR_OK;
-    }
     if (!strcmp(name, "group_xpass")) {
         if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "group_xpass must be -1 (default: on), 0 or 1");
         x.group_xpass = (int)value; drop_graph(x); return BNR_OK;
-    }
-    if (!strcmp(name, "linear_merge")) { x.lin_merge = (int)value; drop_graph(x); return BNR_OK; }
-    if (!strcmp(name, "linear_debug")) { x.lin_debug = (int)value; drop_graph(x); return BNR_OK; }
-    if (!strcmp(name, "linear")) {
-        if (value != 0 && value != 1 && value != 2 && value != 4) return fail(BNR_ERR_BAD_ARG, "linear must be 0 (off), 1, 2 or 4 (parts)");
-        HIPCHK(hipSetDevice(x.device));
-        HIPCHK(hipStreamSynchronize(x.stream));
-        drop_graph(x);
-        while ((int)x.lstreams.size() < (x.lin_merge ? 1 : 2) * (int)value) {
-            hipStream_t st = nullptr;
-            HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            x.lstreams.push_back(st);
-        }
-        if (value && !x.lflags) { HIPCHK(hipMalloc((void **)&x.lflags, sizeof(unsigned long long) * 64)); HIPCHK(hipMemset(x.lflags, 0, sizeof(unsigned long long) * 64)); }
-        x.lin = (int)value;
-        return BNR_OK;
     }
     if (!strcmp(name, "split_sums")) {
         if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "split_sums must be -1 (default: a chain alone), 0 or 1");
@@ -1391,8 +1537,47 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
         x.spw_cap = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "factor_variant")) {
-        if (value < -1 || value > 3) return fail(BNR_ERR_BAD_ARG, "factor_variant must be -1 (auto), 0 (right-looking), 1 (left-looking), 2 (right-looking, two panels per launch) or 3 (2 with the K = 128 trailing update)");
+#ifdef BNR_EXPERIMENTS
+        const bool ok = value >= -1 && value <= 3;
+#else
+        const bool ok = value >= -1 && value <= 3 && value != 1;
+#endif
+        if (!ok) return fail(BNR_ERR_BAD_ARG, "factor_variant must be -1 (auto), 0 (right-looking), 2 (right-looking, two panels per launch) or 3 (2 with the K = 128 trailing update); 1 (left-looking) is an experiment (-DBNR_EXPERIMENTS)");
         x.factor_variant = (int)value; drop_graph(x); return BNR_OK;
+    }
+    if (!strcmp(name, "graph_k")) { if (value < 1 || value > 256) return fail(BNR_ERR_BAD_ARG, "graph_k out of range"); x.graph_k = (int)value; drop_graph(x); return BNR_OK; }
+    if (!strcmp(name, "profiling")) { if (x.profiling != (int)value) drop_graph(x); x.profiling = (int)value; return BNR_OK; }
+#ifdef BNR_EXPERIMENTS
+    if (!strcmp(name, "resv_mask")) {
+        if (value < 0 || (value & ~0xfe) || __builtin_popcountll((unsigned long long)value) > 4) return fail(BNR_ERR_BAD_ARG, "resv_mask: bits 1..7 = cu ids inside a shader engine that the resident Gram leaves free, four at most");
+        x.resv_mask = (int)value; drop_graph(x); return BNR_OK;
+    }
+    if (!strcmp(name, "crit_origin")) {
+        if (value < 0 || value > 2) return fail(BNR_ERR_BAD_ARG, "crit_origin must be 0, 1 or 2");
+        if (value == 2 && !x.stream4) { HIPCHK(hipSetDevice(x.device)); HIPCHK(hipStreamCreateWithFlags(&x.stream4, hipStreamNonBlocking)); }
+        x.crit_origin = (int)value; drop_graph(x); return BNR_OK;
+    }
+    if (!strcmp(name, "group_backproj")) {
+        if (value < 0 || value > 1) return fail(BNR_ERR_BAD_ARG, "group_backproj must be 0 (default) or 1");
+        x.group_backproj = (int)value; drop_graph(x); return BNR_OK;
+    }
+    if (!strcmp(name, "linear_debug")) { x.lin_debug = (int)value; drop_graph(x); return BNR_OK; }
+    if (!strcmp(name, "linear") || !strcmp(name, "linear_merge")) {
+        // the two options size the same stream array: whichever is set last, every stream capture_linear / linear_range index exists
+        const int lin = !strcmp(name, "linear") ? (int)value : x.lin, merge = !strcmp(name, "linear_merge") ? (value ? 1 : 0) : x.lin_merge;
+        if (lin != 0 && lin != 1 && lin != 2 && lin != 4) return fail(BNR_ERR_BAD_ARG, "linear must be 0 (off), 1, 2 or 4 (parts)");
+        if (lin == 4 && !merge) return fail(BNR_ERR_BAD_ARG, "linear = 4 needs linear_merge = 1 (set it first): eight streams on four hardware queues end in gate timeouts (profiles/round3_experiments_notes.txt I)");
+        HIPCHK(hipSetDevice(x.device));
+        HIPCHK(hipStreamSynchronize(x.stream));
+        drop_graph(x);
+        while ((int)x.lstreams.size() < (merge ? 1 : 2) * lin) {
+            hipStream_t st = nullptr;
+            HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            x.lstreams.push_back(st);
+        }
+        if (lin && !x.lflags) { HIPCHK(hipMalloc((void **)&x.lflags, sizeof(unsigned long long) * 64)); HIPCHK(hipMemset(x.lflags, 0, sizeof(unsigned long long) * 64)); }
+        x.lin = lin; x.lin_merge = merge;
+        return BNR_OK;
     }
     if (!strcmp(name, "pipeline")) {
         if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "pipeline must be -1 (auto), 0 or 1");
@@ -1400,8 +1585,7 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
         x.pipeline = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "gate_us")) { if (value < 0 || value > 1000000) return fail(BNR_ERR_BAD_ARG, "gate_us out of range"); x.gate_us = (int)value; drop_graph(x); return BNR_OK; }
-    if (!strcmp(name, "graph_k")) { if (value < 1 || value > 256) return fail(BNR_ERR_BAD_ARG, "graph_k out of range"); x.graph_k = (int)value; drop_graph(x); return BNR_OK; }
-    if (!strcmp(name, "profiling")) { if (x.profiling != (int)value) drop_graph(x); x.profiling = (int)value; return BNR_OK; }
+#endif
     return fail(BNR_ERR_BAD_ARG, std::string("unknown option ") + name);
 }
 static int exec_last_timing(bnr_exec &x, int which, double *avg_us, int64_t *launches)
@@ -1458,10 +1642,10 @@ static int prime_graphs_inner(bnr_exec &x, const std::vector<bnr_chain *> &membe
         rc = upload_plan(c, K + 1, x.stream);
         if (rc) return rc;
     }
-    if (x.nb > 1) {
-        for (size_t i = 0; i < members.size(); ++i) x.cds_pin[i] = members[i]->d;
-        HIPCHK(hipMemcpyAsync(x.cds, x.cds_pin, sizeof(bnr_dev) * members.size(), hipMemcpyHostToDevice, x.stream));
-    }
+    // the device copies of the descriptors (k_setbase / k_advance read them also when the sweep kernels take the struct by value): a GROUP's
+    // array is otherwise only filled by its first run call -- a group of ONE that was prepared before it ran replayed its graphs on garbage
+    for (size_t i = 0; i < members.size(); ++i) x.cds_pin[i] = members[i]->d;
+    HIPCHK(hipMemcpyAsync(x.cds, x.cds_pin, sizeof(bnr_dev) * members.size(), hipMemcpyHostToDevice, x.stream));
     hipLaunchKernelGGL(k_setbase, dim3(x.nb), dim3(1), 0, x.stream, (const bnr_dev *)x.cds, 1);
     for (const auto &r : x.ladder) HIPCHK(hipGraphLaunch(r.gexec, x.stream));
     HIPCHK(hipStreamSynchronize(x.stream));
@@ -1476,6 +1660,7 @@ int bnr_group_prepare(bnr_group *g)
     for (bnr_chain *c : g->m) if (c->d.tot != g->m[0]->d.tot) return fail(BNR_ERR_BAD_ARG, "members of a group must have tables of equal length");
     int rc;
     for (bnr_chain *c : g->m) { rc = ensure_plan(c, ladder_sweeps(g->x) + 1); if (rc) return rc; }   // BEFORE the capture: a regrown plan drops graphs
+    for (size_t i = 0; i < g->m.size(); ++i) g->x.cds_pin[i] = g->m[i]->d;      // the capture's launch choices (group_shares_x: byte_x of the members) read the host copies
     rc = exec_prepare(g->x);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(g->x.stream));
@@ -1770,7 +1955,7 @@ int bnr_chain_resize(bnr_chain *c, int32_t new_tot)
     (void)hipFree(old);
     d.trace = nt; d.tot = new_tot;
     drop_graph(c->x);
-    if (c->group) drop_graph(c->group->x);             // a one-member group bakes the member's descriptor into its graphs as well
+    if (c->group && c->group->x.nb == 1) drop_graph(c->group->x);   // a one-member group bakes the member's descriptor into its graphs as well
     return sync_dev(c);
 }
 
@@ -2169,8 +2354,13 @@ static void launch_gram_only(bnr_chain *c)
 {
     const bnr_dev &d = c->d;
     const int ntl = d.ntile * (d.ntile + 1) / 2;
-    if (c->x.gram_variant == 9) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_one, false>), dim3(BNR_G8P_WPC * c->x.ncu), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1, c->x.gq, (const unsigned *)nullptr, c->x.gctl);
-    else if (c->x.gram_variant == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8<bnr_one>), dim3(round_up(ntl * d.ksplit, 8)), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1);
+#ifdef BNR_EXPERIMENTS
+    if (c->x.gram_variant == 11) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_one, 0>), dim3(3 * c->x.ncu), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1, c->x.gq);
+    else if (c->x.gram_variant == 12) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_one, 1>), dim3(3 * c->x.ncu), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1, c->x.gq);
+    else if (c->x.gram_variant == 9) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_one, false>), dim3(BNR_G8P_WPC * c->x.ncu), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1, c->x.gq, (const unsigned *)nullptr, c->x.gctl);
+    else
+#endif
+    if (c->x.gram_variant == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8<bnr_one>), dim3(round_up(ntl * d.ksplit, 8)), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1);
     else if (d.gram_kg == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), dim3(round_up(ntl * d.ksplit, 8)), dim3(1024), 0, c->x.stream, bnr_one{d}, 0, 1);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 2>), dim3(round_up(ntl * d.ksplit, 8)), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1);
 }
@@ -2198,6 +2388,21 @@ int bnr_chain_debug_time_gram(bnr_chain *c, int32_t reps, double *avg_us)
     return check_launch("debug_time_gram");
 }
 
+// timing experiments (library built with -DBNR_EXPERIMENTS only): flags read by the kernels of the scalar branch, see bnr_exp_flags
+int bnr_debug_set_exp(int32_t device, int32_t flags)
+{
+#ifdef BNR_EXPERIMENTS
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    int v = flags;
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(bnr_exp_flags), &v, sizeof v));
+    return BNR_OK;
+#else
+    (void)device; (void)flags;
+    return fail(BNR_ERR_BAD_ARG, "this library was built without -DBNR_EXPERIMENTS");
+#endif
+}
+
 int bnr_chain_set_profiling(bnr_chain *c, int32_t enable)
 {
     if (!c) return fail(BNR_ERR_BAD_ARG, "NULL chain");
@@ -2215,7 +2420,6 @@ int bnr_chain_set_option(bnr_chain *c, const char *name, int64_t value)
     if (!strcmp(name, "byte_x")) {
         // 0: the X passes read the f64 matrix also when a byte image exists; 1: back to the byte image (if the input had one)
         if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");
-        if (!c->x8_kept) c->x8_kept = c->d.X8;
         c->d.X8 = value ? c->x8_kept : nullptr;
         drop_graph(c->x);
         if (c->group) drop_graph(c->group->x);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Gibbs iterations/s (all chains) of the MI355X hot path on BASELINE.json's headline workload.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: this script starts the N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = one Gibbs sweep (gibbs_sample!, gibbs.jl:663-677) of every chain resident on the GPU.  Workload: synthetic
@@ -106,6 +106,37 @@ class _StdoutToStderr:
         os.close(self.saved)
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): this process becomes the launcher -- it
+    starts N fresh children (one rank per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, as torch.distributed.run would), BEFORE
+    anything here has touched the GPU (nothing is imported but the standard library), relays rank 0's JSON line and returns the first
+    non-zero exit code.  The reference's pmap spawns its workers itself too (gibbs.jl:946-948)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:                              # a free port on the loopback for the ranks' rendezvous
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL across processes)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    out0 = procs[0].communicate()[0]
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=600 if rc == 0 else 20)
+        except subprocess.TimeoutExpired:
+            p.kill()                                          # (our own child, by its pid)
+            p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,7 +150,35 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="0: single-stream schedule (diagnostics)")
     ap.add_argument("--graph-k", type=int, default=0, help="sweeps per captured graph (0: library default)")
     ap.add_argument("--graph", type=int, default=1, help="0: launch every kernel eagerly (diagnostics)")
+    ap.add_argument("--dry-ranks", action="store_true", help="no GPU: every rank only reports which chains it would hold (checks the N-rank plumbing on a CPU)")
     a = ap.parse_args()
+
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a))                           # the parent never touches the GPU: it only starts the ranks and relays rank 0's line
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: the two must agree (one rank per GPU)" % (a.gpus, os.environ["WORLD_SIZE"]))
+    if a.dry_ranks:
+        world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        total_chains = world * a.chains_per_gpu if a.chains_per_gpu > 0 else a.chains
+        ids = [c for c in range(1, total_chains + 1) if (c - 1) % world == rank]
+        line = {"rank": rank, "world": world, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "chain_ids": ids, "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}
+        if world > 1:                                      # the ranks meet over gloo on the loopback, as the real run's rendezvous does
+            import torch.distributed as dist
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            with _StdoutToStderr():                        # gloo reports its connections on stdout; the contract is ONE JSON line there
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                box = [None] * world
+                dist.all_gather_object(box, line)
+                dist.barrier()
+                dist.destroy_process_group()
+            line = {"dry_ranks": box, "n_gpus": world}
+        else:
+            line = {"dry_ranks": [line], "n_gpus": 1}
+        if rank == 0:
+            print(json.dumps(line))
+        return
 
     import numpy as np
     import bnr_amd
@@ -329,7 +388,7 @@ def main():
         out = {
             "metric": "Gibbs iterations/sec (all chains)", "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
-            "scaling": "weak" if (a.chains_per_gpu > 0 or world == 1) else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak" if a.chains_per_gpu > 0 else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "synthetic n=%d V=%d (q=%d) R=%d, %d chains total, %s per GPU" % (n, V, q, R, total_chains, C if total_chains % world == 0 else "%d or %d" % (total_chains // world, total_chains // world + 1))
                                    + ("" if world == 1 else " (BASELINE configs[2]: the %d chains of the fit sharded round-robin over %d GPUs, chain c on rank (c-1) %% %d; "
                                       "the chains of a GPU advance as one lockstep group)" % (total_chains, world, world)),

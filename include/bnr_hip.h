@@ -36,7 +36,9 @@ enum {
     BNR_ERR_BAD_ARG = 1,
     BNR_ERR_HIP = 2,          /* a HIP runtime call failed (no device, out of memory, launch failure ...) */
     BNR_ERR_CHOLESKY = 3,     /* Cholesky failed after the jitter ladder (the reference rethrows: gibbs.jl:337-343) */
-    BNR_ERR_SAMPLER_CAP = 4   /* a rejection sampler hit its attempt cap */
+    BNR_ERR_SAMPLER_CAP = 4   /* a rejection sampler hit its attempt cap: returned ONCE, by the call in which it happened; the rows were written with
+                               * the samplers' fall-backs, the table stays valid, later calls on the chain are not failed for it (the counter
+                               * of bnr_chain_counters keeps the total).  The reference's rejection loops are unbounded and never raise here. */
 };
 
 typedef struct bnr_chain bnr_chain;   /* opaque: one Gibbs chain resident on one GPU */
@@ -221,33 +223,31 @@ int bnr_chain_debug_read(bnr_chain *chain, uint64_t *out, int32_t count);
 int bnr_chain_debug_time_gram(bnr_chain *chain, int32_t reps, double *avg_us);
 /* diagnostics: copy an internal work buffer to the host (0 = factorization matrix E, 1 = rhs b, 2 = a4, 3 = Gram partials) */
 int bnr_chain_debug_copy(bnr_chain *chain, int32_t which, double *out, int64_t count);
+/* timing experiments: only a library built with -DBNR_EXPERIMENTS accepts it (the shipped one returns BNR_ERR_BAD_ARG).  flags bit 0: the
+ * kernels of the scalar branch return at once (results are then NOT the sampler's) -- what the critical chain costs without company */
+int bnr_debug_set_exp(int32_t device, int32_t flags);
 
 /* tunables (performance only; never change results):
  *   "graph"     1 (default): replay captured hipGraphs of graph_k sweeps; 0: launch every kernel eagerly
  *   "graph_k"   sweeps per captured graph (default 8)
  *   "overlap"   1 (default): scalar branch and Gram/factorization branch of a sweep on two streams; 0: one stream
  *   "gram_variant" 0 (default): the Gram kernel is chosen per launch (k_gram8 when the launch has more than two workgroups per CU,
- *               k_gram otherwise); 8 / 16 force one of them; 9: the persistent kernel k_gram8p, 10: k_gram8d (the unscaled panel by LDS-DMA) --
- *               experiments, measured slower.  All write the same partial tiles bit for bit.
+ *               k_gram otherwise); 8 / 16 force one of them.  Both write the same partial tiles bit for bit.  (9..14: the persistent /
+ *               resident experiments of csrc/bnr_experiments.h, accepted only by a library built with -DBNR_EXPERIMENTS.)
  *   "profiling" 1: record HIP events around every k_gram launch (forces eager launches), see bnr_chain_last_timing
  *   "factor_variant" -1 (default): chosen by size -- 0 below n_pad = 1024, 3 from there on; 0: right-looking factorization, one
- *               32-column panel per launch (k_gram_reduce + k_chol_step); 1: left-looking (k_chol_ll); 2: right-looking, two panels per
- *               launch (k_chol_step2); 3: 2 with the whole trailing matrix updated at every other launch only (K = 128)
+ *               32-column panel per launch (k_gram_reduce + k_chol_step); 2: right-looking, two panels per launch (k_chol_step2); 3: 2 with
+ *               the whole trailing matrix updated at every other launch only (K = 128); (1: left-looking k_chol_ll, -DBNR_EXPERIMENTS only)
  *   "fuse_reduce" 1 / -1 (default): launch 0 of the one-panel factorization also sums the Gram's K-split partial tiles (no k_gram_reduce
  *               launch); 0: separate reduction pass
  *   "group_xpass" -1 (default): a lockstep group whose members share the device copy of X (bnr_chain_create_like) runs ONE X pass
- *               for all members (k_xpass_group) when X has 8 MB or more per chain; 1: always; 0: one pass per member.  "group_backproj" 1: the same for the back-projection / GIG kernel
- *               (default 0: measured no faster)
+ *               for all members (k_xpass_group) when X has 8 MB or more per chain; 1: always; 0: one pass per member
  *   "split_sums" -1 (default): a chain run alone computes the back-projection's partial sums (update_theta!, update_Lambda!) in a launch of
  *               their own in front of the scalar tail, off the critical chain; 1: always; 0: inside the back-projection
  *   "spw_cap"   1..4 (default 4): super blocks per update workgroup of the factorization, at most (diagnostics)
- *   "linear"    (groups; opt-in, experimental) 1 / 2 / 4: every stream replays LINEAR captured graphs and the streams meet through device
- *               counters (gate / setter kernels); with 2 or 4 the members advance as that many phase-shifted parts, one part's Gram beside
- *               the others' factorizations.  "linear_merge" 1 (set BEFORE "linear"): one stream per part.  Bitwise the default's tables;
- *               measured no faster (profiles/round3_experiments_notes.txt I); needs its streams on distinct hardware queues (four exist) --
- *               otherwise the run ends with "stream ordering violated".  0 (default): off
- *   "pipeline"  1 (needs factor_variant 1): factorization beside the Gram (persistent Gram off the reserved CUs, gates per tile column)
- *   "gate_us"   how long a gate of the pipelined schedule polls before it gives up (default 3000)
+ *   Experiments ("pipeline", "gate_us", "linear", "linear_merge", "linear_debug", "group_backproj", "resv_mask", "crit_origin"; rounds 3-4,
+ *               profiles/round*_experiments_notes.txt): all measured no faster, part of them poll device memory.  They exist only in a library
+ *               built with -DBNR_EXPERIMENTS (csrc/bnr_experiments.h, tools/r4_build_variants.sh); the shipped library refuses them by name.
  *   "byte_x"    (chains only) 0: the X passes read the f64 matrix although a byte image of X exists; 1 (default): the byte image
  *               (kept when the model matrix came as Bool/UInt8, or as Int32/Int64 with every value in 0..255; docs/src/man/inputdata.md)
  * All variants give the same tables bit for bit.  bnr_chain_last_timing(which = 3) says whether a byte image is in use. */

@@ -664,6 +664,11 @@ def test_byte_image_of_a_binary_model_matrix_at_config5_size(gpu):
             if want is not None:
                 assert np.array_equal(tabs[0][k], want[k]), (name, k)
         want = want or tabs[0]
+    # ... and they are the ORACLE's tables on the same 0/1 data (round 3 compared the library with itself here): the prior draw and two sweeps
+    o = bo.Oracle(np.asfortranarray(Xb.astype(np.float64)), y, R, 3, 21, chain=1, pdf_mode=1)
+    o.init_prior()
+    o.run(2, 3, 3)
+    assert_tables_close({k: v[:3] for k, v in want.items()}, o.t, what="0/1 model matrix at config-5 size (byte image) vs oracle")
 
 
 def test_device_summary_equals_host_summary(gpu, test1):
@@ -1151,6 +1156,11 @@ def test_device_reports_the_sampler_cap(gpu):
     o.update("theta", 1, 2)
     assert e.value.code == 4 == o.status
     assert ch.counters()["sampler_cap"] >= 1
+    # ... reported by the call in which it happened and only by that one: the device counter is cumulative, the rows were written with the
+    # samplers' fall-backs and the table stays usable (the reference's rejection loops are unbounded and never raise here) -- the next
+    # call on the chain succeeds, the counter keeps the total
+    ch.update("Delta", 2, 2)
+    assert ch.counters()["sampler_cap"] >= 1
     ch.close()
 
 
@@ -1184,14 +1194,66 @@ def test_post_burn_in_rows_match_the_oracle_at_config3(gpu):
         c.close()
 
 
+def test_experimental_options_are_refused_by_the_shipped_library(gpu, test1):
+    """The measured experiments of rounds 3 and 4 (left-looking factorization behind progress gates, persistent / resident Gram kernels with task
+    queues and reserved CUs, the pipelined and "linear" schedules, the group back-projection: csrc/bnr_experiments.h) are compiled only with
+    -DBNR_EXPERIMENTS; part of them poll device memory.  The library a user loads has none of them: every option that would select one is
+    refused by name, for a chain and for a group, and the chain works on as before."""
+    X, y = test1
+    ch = bnr_amd.Chain(X, y, 5, 8, 3, 1)
+    mate = bnr_amd.Chain.like(ch, 3, 2, 8)
+    g = bnr_amd.Group([ch, mate])
+    for target in (ch, g):
+        for name, value in (("pipeline", 1), ("linear", 2), ("linear_merge", 1), ("gate_us", 100), ("group_backproj", 1), ("resv_mask", 0x80),
+                            ("crit_origin", 1), ("gram_variant", 9), ("gram_variant", 10), ("gram_variant", 13), ("factor_variant", 1)):
+            with pytest.raises(bnr_amd.BnrError, match="BNR_EXPERIMENTS"):
+                target.set_option(name, value)
+    assert bnr_amd.lib().bnr_debug_set_exp(0, 1) != 0
+    for c in (ch, mate):
+        c.init_prior()
+    g.run(2, 8, 8)
+    assert ch.counters()["chol_fail"] == 0 and np.isfinite(ch.fetch()["gamma"]).all()
+    g.close()
+    ch.close(); mate.close()
+
+
+def test_group_of_one_survives_a_resize(gpu, test1):
+    """A lockstep group with ONE member issues its kernels with the member's descriptor by value, baked into the group's captured graphs
+    (bnr_one): resizing the member's table (generate_samples_dbl! re-allocates it every round, gibbs.jl:1164-1172) must drop those graphs too
+    (bnr_hip.hip, bnr_chain_resize / ensure_plan).  Group of one: run, resize, run == the same chain run alone, bitwise."""
+    X, y = test1
+    solo = bnr_amd.Chain(X, y, 5, 40, 17, 1)
+    solo.init_prior()
+    solo.run(2, 20, 20)
+    solo.resize(40 + 25)
+    solo.run(21, 65, 65)
+    want = solo.fetch()
+    ch = bnr_amd.Chain.like(solo, 17, 1, 40)
+    ch.init_prior()
+    g = bnr_amd.Group([ch])
+    g.prepare()                           # (round 4: a group of ONE prepared before its first run replayed its graphs on an unfilled descriptor array)
+    g.run(2, 20, 20)                      # replays the group's graphs (descriptor of the 40-row table inside)
+    ch.resize(40 + 25)                    # new trace allocation: stale graphs would write into freed memory
+    g.run(21, 65, 65)                     # (no prepare in between: a prepare re-derives the carried sums, equal only to rounding)
+    got = ch.fetch()
+    for k in bo.COLUMNS:
+        assert np.array_equal(got[k], want[k]), k
+    # a plan longer than the chain's first allocation regrows it (ensure_plan): the group's graphs are dropped there as well
+    ch.resize(70000)
+    g.prepare()
+    g.run(66, 69999, 69999)
+    assert ch.counters()["chol_fail"] == 0 and np.isfinite(ch.fetch(69999, 69999)["gamma"]).all()
+    g.close()
+    ch.close(); solo.close()
+
+
 def test_factorization_variants_are_bitwise_equal(gpu):
-    """The opt-in factorizations of round 3 -- left-looking k_chol_ll (K-split partials summed on the first touch, no k_gram_reduce, four
-    sweeping waves per workgroup) and k_chol_step2 (two panels per launch; variant 3: the trailing matrix updated every other launch with K = 128) -- give bitwise the tables of the default right-looking
-    path (gibbs.jl:434), alone and as members of a lockstep group, from graphs and eagerly; so does the default's first launch, which sums the
-    Gram's K-split partial tiles itself (fuse_reduce), against the separate k_gram_reduce pass, and the group's X pass with one workgroup per
-    column chunk for all members (group_xpass) against the per-chain kernel, and so does the opt-in back-projection / GIG kernel with one workgroup
-    per block of edges for eight members (group_backproj: the later rounds of its rejection samplers share the wave among the open edges).  (The persistent Gram k_gram8p and the
-    pipelined schedule that builds on it are checked the same way by tools/ab_factor.py, outside this suite: they poll device flags.)"""
+    """k_chol_step2 (two panels per launch; variant 3: the trailing matrix updated every other launch with K = 128) gives bitwise the tables of the
+    default right-looking path (gibbs.jl:434), alone and as members of a lockstep group, from graphs and eagerly; so does the default's first
+    launch, which sums the Gram's K-split partial tiles itself (fuse_reduce), against the separate k_gram_reduce pass, and the group's X pass
+    with one workgroup per column chunk for all members (group_xpass) against the per-chain kernel, and the partial sums as a launch of their
+    own (split_sums).  (The experimental variants -- left-looking factorization, resident Gram kernels, pipelined schedule, group
+    back-projection -- are checked the same way by tools/ab_factor.py against a -DBNR_EXPERIMENTS build, outside this suite.)"""
     for (n, V, R) in [(70, 19, 5), (193, 30, 5), (64, 9, 2), (500, 40, 4), (1000, 12, 3)]:
         X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=7)
         tabs = {}
@@ -1200,8 +1262,6 @@ def test_factorization_variants_are_bitwise_equal(gpu):
                            ("right, X pass per chain", {"factor_variant": 0, "group_xpass": 0}),
                            ("right, X pass for the group", {"factor_variant": 0, "group_xpass": 1}),
                            ("right, sums split off", {"factor_variant": 0, "split_sums": 1}), ("right, sums inside", {"factor_variant": 0, "split_sums": 0}),
-                           ("right, back-projection for the group", {"factor_variant": 0, "group_backproj": 1}),
-                           ("left", {"factor_variant": 1}), ("left, eager", {"factor_variant": 1, "graph": 0}),
                            ("two panels", {"factor_variant": 2}), ("two panels, eager", {"factor_variant": 2, "graph": 0}),
                            ("two panels, K = 128 trailing update", {"factor_variant": 3}), ("two panels, K = 128, eager", {"factor_variant": 3, "graph": 0})):
             ch = bnr_amd.Chain(X, y, R, 6, 3, 1)

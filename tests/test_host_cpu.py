@@ -2,6 +2,7 @@
 its host copies of the draw-site primitives equal the oracle's bit for bit, the split-Rhat finish equals rhat(),
 the reference-interface helpers behave as the reference's, and the multi-rank Rhat exchange works over gloo.
 No compute call is made (there is no GPU here); the GPU path is covered by the -m gpu tests."""
+import json
 import os
 import re
 import socket
@@ -261,6 +262,33 @@ def test_rhat_exchange_two_ranks_gloo(tmp_path, num_chains):
     assert np.array_equal(r0, r1)
     ref = np.stack([np.random.default_rng(100 + c).random(36) for c in range(1, num_chains + 1)])
     assert np.allclose(r0, bnr_amd.rhat_from_stats(ref, 20))
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus N` as the driver types it (no launcher, no WORLD_SIZE): the script itself starts one fresh process per GPU --
+    before anything touched the GPU -- with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, chain c on rank (c-1) % N (the reference's pmap
+    spawns its workers itself, gibbs.jl:946-948), and relays rank 0's ONE line.  --dry-ranks: no GPU, every rank only reports what it
+    would hold (the ranks still meet over gloo on the loopback)."""
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-ranks"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["dry_ranks"]) == 2
+    r0, r1 = sorted(d["dry_ranks"], key=lambda r: r["rank"])
+    assert (r0["rank"], r0["local_rank"], r0["world"], r0["chain_ids"]) == (0, 0, 2, [1, 3, 5, 7])
+    assert (r1["rank"], r1["local_rank"], r1["world"], r1["chain_ids"]) == (1, 1, 2, [2, 4, 6, 8])
+    assert r0["master"] == r1["master"] and r0["master"].startswith("127.0.0.1:")
+    # three ranks, five chains: the round-robin of api.local_chain_ids
+    out = subprocess.run([sys.executable, bench, "--gpus", "3", "--chains", "5", "--dry-ranks"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout.strip())
+    assert [r["chain_ids"] for r in sorted(d["dry_ranks"], key=lambda r: r["rank"])] == [[1, 4], [2, 5], [3]]
+    # a launcher that started a different number of ranks than --gpus says: refused, loudly
+    out = subprocess.run([sys.executable, bench, "--gpus", "4", "--dry-ranks"], env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "must agree" in out.stderr
 
 
 def test_chains_are_refused_when_a_foreign_hip_runtime_was_loaded_first(tmp_path):

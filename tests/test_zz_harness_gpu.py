@@ -69,6 +69,21 @@ def test_bench_multi_rank_path_rehearsal(gpu, tmp_path):
     assert d["timed_region"]["sweeps_launched_eagerly"] == 0 and d["timed_region"]["sweeps_replayed_from_graphs"] == 40
 
 
+def test_bench_plain_command_starts_two_ranks(gpu):
+    """The driver's own spelling, `python bench.py --gpus 2 ...` with no launcher in front: bench.py starts the two ranks itself (fresh
+    children, before the parent touched the GPU) and relays rank 0's line -- rehearsed on this one GPU (BNR_BENCH_ONE_DEVICE=1)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BNR_BENCH_ONE_DEVICE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "4", "--config", "cfg2", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, "rc %d\n%s" % (out.returncode, out.stderr[-6000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 24 and d["scaling"] == "strong" and d["config"]["chains_per_gpu"] == 4 and d["value"] > 0
+    assert d["timed_region"]["sweeps_replayed_from_graphs"] == 24
+
+
 def test_bench_one_rank_rccl_path(gpu, tmp_path):
     """The N > 1 path of bench.py on hardware with ONE rank under torch.distributed.run: rendezvous over gloo, the library's own RCCL
     communicator (ncclCommInitRank of world size 1), the timing's max over ranks and bnr_rhat's exchange -- k_rhat_stats writes the

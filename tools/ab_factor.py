@@ -2,6 +2,7 @@
 """Development check: the left-looking factorization (factor_variant 1) gives bitwise the tables of the right-looking one
 (factor_variant 0), alone and in a lockstep group, over ragged shapes; plus the time per sweep of both at the headline size."""
 import sys, os, time
+os.environ.setdefault("BNR_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bayesiannetworkregression.jl_amd", "csrc", "_var", "exp.so"))   # the experiments build (tools/r4_build_variants.sh)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bnr_amd
@@ -33,7 +34,10 @@ def tables(n, V, R, variant, rows=6, extra=None):
 bad = 0
 for (n, V, R) in [(70, 19, 5), (500, 100, 7), (130, 12, 3), (64, 9, 2), (193, 30, 5), (1, 5, 2), (33, 2, 1), (1000, 40, 4), (2000, 12, 3)]:
     t0 = tables(n, V, R, 0)
-    for name, fv, extra in (("two panels per launch", 2, {}), ("left", 1, {"pipeline": 0}), ("left+persistent gram", 1, {"pipeline": 0, "gram_variant": 9}), ("pipelined", 1, {"pipeline": 1})):
+    for name, fv, extra in (("two panels per launch", 2, {}), ("left", 1, {"pipeline": 0}), ("left+persistent gram", 1, {"pipeline": 0, "gram_variant": 9}), ("pipelined", 1, {"pipeline": 1}),
+                            ("static resident Gram", 0, {"gram_variant": 11}), ("static resident Gram, queue order", 0, {"gram_variant": 14}),
+                            ("resident Gram, per-CU lists, cu 7 reserved", 0, {"gram_variant": 13, "resv_mask": 0x80}), ("critical chain on the origin queue", 0, {"crit_origin": 1}),
+                            ("group back-projection", 0, {"group_backproj": 1})):
         t1 = tables(n, V, R, fv, extra=extra)
         for k in bo.COLUMNS:
             for i, what in ((0, "group"), (1, "alone")):

@@ -1,5 +1,6 @@
 """Bitwise check of the linear schedule (option linear = 1 / 2 / 4) against the default schedule: a lockstep group of 8 chains, 70 sweeps."""
 import sys, os
+os.environ.setdefault("BNR_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bayesiannetworkregression.jl_amd", "csrc", "_var", "exp.so"))   # the experiments build (tools/r4_build_variants.sh)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bnr_amd
 n, V, R = (int(v) for v in os.environ.get("BNR_SHAPE", "500,100,7").split(","))

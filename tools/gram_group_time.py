@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Gram launch time of an 8-chain group (HIP events around the launch, eager) for kernel variants / schedules."""
 import sys, os, time
+os.environ.setdefault("BNR_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bayesiannetworkregression.jl_amd", "csrc", "_var", "exp.so"))   # the experiments build (tools/r4_build_variants.sh)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bnr_amd
 X, y, _ = bnr_amd.make_synthetic(500, 100, 7, seed=20240501)

@@ -1,6 +1,7 @@
 """Timeline of the linear schedule from the gates' and setters' own clocks (option linear_debug): per sweep and part, relative to the ring gate of part 0 (us):
 S gate in/out (scalar branch may start), rhs done | ring gate in/out (Gram start), Gram done, solve gate in/out (factorization done / rhs there), back-projection done."""
 import sys, os
+os.environ.setdefault("BNR_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bayesiannetworkregression.jl_amd", "csrc", "_var", "exp.so"))   # the experiments build (tools/r4_build_variants.sh)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bnr_amd
 P = int(sys.argv[1]); extra = sys.argv[2:]

@@ -2,6 +2,7 @@
 """Development: one configuration of the sweep schedule on a small group, printed step by step (run under `timeout`).
 usage: stage_test.py <factor_variant> <pipeline> <gram_variant> <graph> [n V R]"""
 import sys, os
+os.environ.setdefault("BNR_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bayesiannetworkregression.jl_amd", "csrc", "_var", "exp.so"))   # the experiments build (tools/r4_build_variants.sh)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bnr_amd

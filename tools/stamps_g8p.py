@@ -1,5 +1,6 @@
 """Diagnostic: per-task stamps of three persistent Gram workgroups (build with -DBNR_STAMPS)."""
 import sys, os
+os.environ.setdefault("BNR_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bayesiannetworkregression.jl_amd", "csrc", "_var", "stamps.so"))   # the experiments build (tools/r4_build_variants.sh)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bnr_amd
 X, y, _ = bnr_amd.make_synthetic(500, 100, 7, seed=20240501)
