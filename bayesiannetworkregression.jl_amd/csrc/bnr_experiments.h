@@ -126,16 +126,6 @@ struct bnr_gramq { int qoff[9]; };                    // per-XCD task list x = g
 // never gets older than its neighbours, and the arbiter serves equal priorities oldest-first).
 __device__ __forceinline__ unsigned bnr_hw_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v)); return v; }
 __device__ __forceinline__ unsigned bnr_xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 7u; }
-// wave-uniform values pinned to scalar registers (v_readfirstlane): inside a task loop the compiler cannot use scalar loads for what it
-// reads after the first store of the kernel, and a uniform value left in a vector register drags the address arithmetic built on it there too
-__device__ __forceinline__ int bnr_sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
-template <class T>
-__device__ __forceinline__ T *bnr_sgpr_global(T *p)
-{
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return (T *)(__attribute__((address_space(1))) void *)(((unsigned long long)hi << 32) | lo);
-}
 template <class SRC, int ROT>
 __global__ __launch_bounds__(512, 6) void k_gram8s(const SRC chain_src, int s, int nchains, bnr_gramq gq)
 {
@@ -1004,3 +994,191 @@ __global__ __launch_bounds__(64) void k_lin_gate(const unsigned long long *flag,
 __global__ void k_stamp(unsigned long long *dbg, int slot) { if (threadIdx.x == 0) dbg[slot] = __builtin_amdgcn_s_memrealtime(); }
 
 __global__ void k_zero_words(unsigned *p, int n) { for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u; }
+
+// ----------------------------------------------------------------------------------------- data-flow factorization (n_pad <= 512)
+// k_chol_df: the SAME factorization of E = [G + I ; I] -> [L ; L^-T] as k_chol_step x nbk -- every element sees the K-slice partials summed in
+// k_gram_reduce's order, then the panels' rank-32 updates in ascending order (eight MFMA k-steps each), then the same column sweep: bitwise the
+// same E -- as ONE launch in which the panel steps follow each other through flags instead of kernel boundaries.  What a boundary costs inside a
+// captured graph: ~2.3 us from one launch to the next + a cold round trip to memory for the fragments (1.35 us), x 16 steps = 58 of the 112 us of
+// one chain's factorization (141 us for a group of 8); measured ceiling of what a faster factorization buys: tools/r4_exp3.py.
+//   ONE CHAIN PER XCD.  The workgroups of the launch are dealt round-robin to the XCDs (workgroup i -> XCD i % 8): chain c = i % 8, local index
+//   w = i / 8.  Everything the workgroups of a chain hand to each other travels through THAT XCD's L2 -- plain stores (the L1 is write-through) +
+//   s_waitcnt vmcnt(0), a flag written by an atomic the L2 executes (workgroup scope: no sc bits), fragments and flags read past the reader's L1
+//   (sc1 loads): 0.95 us per hand-over, no cache maintenance at all (tools/xcd_sync_probe.hip; through memory across XCDs: 1.4 us + cold loads).
+//   Every workgroup reports its XCD (dfctl[1]); k_solve_w checks that a chain saw exactly one and raises "stream ordering violated" otherwise.
+//   OWNER COMPUTES.  The nbk blocks of block column j that are swept (matrix rows j+1.., identity rows 0..j; the diagonal block itself is needed by
+//   nobody afterwards) are "slots" 0..nbk-1; workgroup w = (slot = w % 16, group = w / 16) owns slot `slot` of the columns group, group + 4,
+//   group + 8, group + 12: at most four 32 x 32 blocks, kept as MFMA accumulator tiles in the registers of its four waves from their first touch
+//   (the K-slice partials) to their sweep, together with an own copy of each column's diagonal block (it takes the same panels' updates from
+//   the same fragments) -- the trailing matrix never goes through memory.  At step q the owners of column q sweep [D ; own] (bnr_panel_sweep),
+//   store the swept block to E and raise its flag; everybody who still holds a block of a later column waits for the two blocks of panel q it
+//   needs and applies the update.  Nobody waits for anything but panels of lower index: with all workgroups resident (64 per chain, two per CU:
+//   512 of 256 threads at most) the launch always ends; a wait that outlasts BNR_DF_TIMEOUT_US gives up and raises the status.
+//   grid = 8 x 64 workgroups of 256 threads; lockstep groups of up to 8 chains (more: k_chol_step).
+#define BNR_DF_WG 64
+#define BNR_DF_TIMEOUT_US 200000
+__device__ __forceinline__ double bnr_ld_l2(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the wave's 16 x 16 tile (columns mt, rows nt) of a 32 x 32 block kept in LDS (row + BNR_LP * column, like the sweep's staging area)
+__device__ __forceinline__ bnr_d4 bnr_lds_tile_get(const double *sX, int mt, int nt, int ln, int lq)
+{
+    bnr_d4 c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = sX[(nt * 16 + ln) + BNR_LP * (mt * 16 + lq + 4 * r)];
+    return c;
+}
+__device__ __forceinline__ void bnr_lds_tile_put(double *sX, int mt, int nt, int ln, int lq, const bnr_d4 &c)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sX[(nt * 16 + ln) + BNR_LP * (mt * 16 + lq + 4 * r)] = c[r];
+}
+// panel q into one owned block (register tile cB) and into the LDS copy of its column's diagonal block.  The two blocks of the panel it takes --
+// L[j, q] (column side of both products, row side of the diagonal copy's) and L[br, q] -- are brought from the L2 ONCE per workgroup into the
+// sweep's staging area (free between sweeps) and read from there as MFMA fragments: fetched per wave straight from the L2, every wave loaded
+// three 4 KiB fragments = 48 KiB per update for 16 KiB of data, and with ~200 live blocks per chain and step the XCD's L2 bandwidth set the pace
+// (9.6 MB per step: 10 us per step instead of 5).
+// An identity row r has no block in the panels q < r: what is read there is the part of E below the block diagonal of Y, which no kernel ever
+// writes (zeros since the allocation) -- the update then subtracts exact zeros, as k_chol_step's does for the same blocks.  (Unconditional on
+// purpose: with a branch around the second group of MFMAs the group instantiation of this kernel computed wrong diagonal copies -- the
+// accumulators live in AGPRs here and the taken branch reached their v_accvgpr_read too early.)
+__device__ __forceinline__ void bnr_df_update(bnr_panel_lds &sh, const double *E, size_t ld, int q, int j, int br, bnr_d4 &cB, double *sDj, int mt, int nt, int tid)
+{
+    const int lane = tid & 63, ln = lane & 15, lk = lane >> 4;
+    const size_t kc = ld * (size_t)(q * BNR_NB);
+    // thread t brings elements (row t % 32, columns t / 32 + 8 i) of both blocks
+    const int sr = tid & 31, sc = tid >> 5;
+    const double *pj = E + (size_t)(j * BNR_NB + sr) + kc + ld * (size_t)sc, *pb = E + (size_t)(br * BNR_NB + sr) + kc + ld * (size_t)sc;
+    double vj[4], vb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { vj[i] = bnr_ld_l2(pj + ld * (size_t)(8 * i)); vb[i] = bnr_ld_l2(pb + ld * (size_t)(8 * i)); }
+    __syncthreads();                                      // (whoever still reads the staging area of the previous update is done)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sh.sD[sr + BNR_LP * (sc + 8 * i)] = vj[i]; sh.sB[sr + BNR_LP * (sc + 8 * i)] = vb[i]; }
+    __syncthreads();
+    double av[8], dv[8], bv[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        av[ks] = sh.sD[(mt * 16 + ln) + BNR_LP * (4 * ks + lk)]; dv[ks] = sh.sD[(nt * 16 + ln) + BNR_LP * (4 * ks + lk)]; bv[ks] = sh.sB[(nt * 16 + ln) + BNR_LP * (4 * ks + lk)];
+    }
+    bnr_d4 cD = bnr_lds_tile_get(sDj, mt, nt, ln, lk);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) cD = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[ks], dv[ks], cD, 0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) cB = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[ks], bv[ks], cB, 0, 0, 0);
+    bnr_lds_tile_put(sDj, mt, nt, ln, lk, cD);
+    bnr_wsync();                                          // (a ds_write is not ordered before later ds_reads of the same wave without the wait)
+}
+// two flags at once (one round trip per poll instead of two in a row)
+__device__ __forceinline__ bool bnr_df_wait2(const unsigned int *f0, const unsigned int *f1, unsigned int epoch)
+{
+    unsigned a = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a == epoch && b == epoch) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        a = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); b = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a == epoch && b == epoch) return true;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 100ull * BNR_DF_TIMEOUT_US) return false;
+    }
+}
+template <class SRC>
+__global__ __launch_bounds__(256) void k_chol_df(const SRC chain_src, int s, int nchains)
+{
+    BNR_CRITICAL_PATH();
+    const int chain = blockIdx.x & 7, w = blockIdx.x >> 3;
+    if (chain >= nchains) return;
+    const bnr_dev &cd = chain_src.at(chain);
+    __shared__ bnr_panel_lds sh;
+    __shared__ double sDc[4][BNR_NB * BNR_LP];            // my copies of the diagonal blocks of my four columns
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nbk = cd.n_pad / BNR_NB;
+    const int slot = w & 15, grp = w >> 4;
+    if (slot >= nbk) return;
+    const size_t ld = bnr_ldE(cd.n_pad);
+    const int mt = wave >> 1, nt = wave & 1, ln = lane & 15, lq = lane >> 4;
+    double *E = cd.E;
+    const unsigned int epoch = cd.dfctl[0];
+    unsigned int *flags = cd.dfctl + 32;
+    if (tid == 0) {
+        unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+        __hip_atomic_fetch_or(&cd.dfctl[1], 1u << (v & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // my blocks: column j_k = grp + 4 k; block row: matrix row j + 1 + slot while there are any, then identity row slot - (nbk - 1 - j)
+    bnr_d4 cB[4];
+    int brow[4];                                         // block row in E (matrix rows 0 .. nbk-1, identity rows nbk ..); -1: no block
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = grp + 4 * k;
+        brow[k] = -1;
+        cB[k] = bnr_d4{0.0, 0.0, 0.0, 0.0};
+        if (j < nbk) {
+            const int nmat = nbk - 1 - j;
+            bnr_d4 t1[1][1];
+            if (slot < nmat) {
+                brow[k] = j + 1 + slot;
+                bnr_gsum_frag<1>(cd, brow[k], j, mt, nt, ln, lq, t1, false);
+                cB[k] = t1[0][0];
+            } else {
+                brow[k] = nbk + (slot - nmat);
+                if (slot - nmat == j) {                  // the identity block itself
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cB[k][r] = (nt * 16 + ln == mt * 16 + lq + 4 * r) ? 1.0 : 0.0;
+                }
+            }
+            bnr_gsum_frag<1>(cd, j, j, mt, nt, ln, lq, t1, false);
+            bnr_lds_tile_put(sDc[k], mt, nt, ln, lq, t1[0][0]);      // (every wave reads back only the tile it wrote: no barrier needed)
+            bnr_wsync();
+        }
+    }
+    int bad = 0, late = 0;
+#ifdef BNR_STAMPS
+#define BNR_DSTAMP(i) do { if (slot == 0 && chain == 0 && tid == 0) cd.dbg[400 + 8 * q + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BNR_DSTAMP(i) do { } while (0)
+#endif
+    // Order of work per panel p (p = -1: nothing to apply yet): FIRST panel p into my block of column p + 1 (its owner is the next sweeper), then,
+    // if I own one, that block's sweep at once; only then panel p into my blocks of the columns behind.
+    for (int p = -1; p < nbk; ++p) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (p >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = grp + 4 * k;
+                    if (j <= p || j >= nbk || brow[k] < 0) continue;
+                    if ((pass == 0) != (j == p + 1)) continue;
+                    // L[j, p] and my block row of panel p (an identity row r has one only from p = r on: before that the update reads zeros)
+                    const bool has_b = brow[k] < nbk || brow[k] - nbk <= p;
+                    if (!bnr_df_wait2(&flags[32 * p + j], &flags[32 * p + (has_b ? brow[k] : j)], epoch)) late = 1;
+                    asm volatile("" ::: "memory");                                          // (the fragment loads stay behind the flags they wait for)
+                    bnr_df_update(sh, E, ld, p, j, brow[k], cB[k], sDc[k], mt, nt, tid);
+                    __builtin_amdgcn_sched_barrier(0);                                      // (one block at a time: the fragments of several updates would be live at once)
+                }
+            }
+            const int q = p + 1;                                                            // the column that is complete now
+            if (pass == 0 && q < nbk && (q & 3) == grp) {
+#ifdef BNR_STAMPS
+                if (slot == 0 && chain == 0 && tid == 0) { cd.dbg[400 + 8 * q + 4] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+                const int k = q >> 2;
+                bnr_d4 sB = cB[0];
+                int br = brow[0];
+                if (k == 1) { sB = cB[1]; br = brow[1]; } else if (k == 2) { sB = cB[2]; br = brow[2]; } else if (k == 3) { sB = cB[3]; br = brow[3]; }
+                if (br >= 0) {
+                    double *dst = E + (size_t)(br * BNR_NB) + ld * (size_t)(q * BNR_NB);
+                    const bnr_d4 sD = bnr_lds_tile_get(sDc[k], mt, nt, ln, lq);
+                    __syncthreads();                                                       // (the staging area may still be read by the last update's fragments)
+                    BNR_DSTAMP(1);
+                    bad |= bnr_panel_sweep(sh, sD, sB, tid, dst, ld);
+                    BNR_DSTAMP(2);
+                    if (wave == 0) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the swept block is in the L2 ...
+                        if (lane == 0) __hip_atomic_exchange(&flags[32 * q + br], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ... then its flag (an atomic the L2 executes)
+                    }
+                    __syncthreads();                                                       // (the staging area of the sweep is free again)
+                    BNR_DSTAMP(3);
+                }
+            }
+        }
+    }
+    if (bad && tid == 0 && w == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[7], 1ull); }
+    if (late && lane == 0) atomicAdd((unsigned long long *)&cd.counters[8], 1ull);       // a hand-over never came: the run fails loudly ("stream ordering violated")
+}

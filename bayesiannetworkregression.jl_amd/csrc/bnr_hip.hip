@@ -127,7 +127,10 @@ static int dev_alloc(bnr_chain *c, T **p, size_t count, bool zero = true)
 {
     void *q = nullptr;
     HIPCHK(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
-    if (zero) HIPCHK(hipMemset(q, 0, std::max<size_t>(count, 1) * sizeof(T)));
+    // zeroed ON THE CHAIN'S OWN STREAM: the streams of this library are non-blocking, i.e. not ordered with the legacy stream a plain
+    // hipMemset runs on -- a fill that is still pending there when the first kernels of the chain start would wipe what they wrote
+    // (seen under rocprofv3 --pmc, which delays dispatches: first run of a fresh chain "Cholesky failed" in every node, round 4 notes)
+    if (zero) HIPCHK(hipMemsetAsync(q, 0, std::max<size_t>(count, 1) * sizeof(T), c->x.stream));
     c->allocs.push_back(q);
     *p = (T *)q;
     return BNR_OK;
@@ -211,7 +214,7 @@ static int alloc_trace(bnr_chain *c, int tot, double **out)
     // (enqueue_run) and of the discarded sweeps that prime the captured graphs (prime_graphs)
     size_t bytes = (size_t)(tot + 2) * c->d.rowlen * sizeof(double);
     HIPCHK(hipMalloc(&p, bytes));
-    HIPCHK(hipMemset(p, 0, bytes));
+    HIPCHK(hipMemsetAsync(p, 0, bytes, c->x.stream));       // (on the chain's stream, see dev_alloc)
     *out = (double *)p;
     c->trace_bytes = bytes;
     return BNR_OK;
@@ -357,7 +360,8 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
         auto in_alloc = [&](void **ptr, size_t bytes) -> int {
             HIPCHK(hipMalloc(ptr, std::max<size_t>(bytes, 8)));
             c->in->bufs.push_back(*ptr);
-            HIPCHK(hipMemset(*ptr, 0, std::max<size_t>(bytes, 8)));
+            HIPCHK(hipMemsetAsync(*ptr, 0, std::max<size_t>(bytes, 8), c->x.stream));
+            HIPCHK(hipStreamSynchronize(c->x.stream));       // the (synchronous, legacy-stream) uploads below must find the zeros in place
             return BNR_OK;
         };
         TRY(in_alloc((void **)&Xd, sizeof(double) * (size_t)d.n_pad * (d.q_pad + 64)));   // + 64 zero columns: the Gram prefetch may run 5 batches past a slice
@@ -468,7 +472,10 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     TRY(dev_alloc(c, &d.counters, 16));
     TRY(dev_alloc(c, &d.stamp, 8 * ntl));
     TRY(dev_alloc(c, &d.gprog, d.ntile + 4));
-    TRY(dev_alloc(c, &d.dbg, 1024));
+#ifdef BNR_EXPERIMENTS
+    TRY(dev_alloc(c, &d.dfctl, 32 + 32 * 16));
+#endif
+    TRY(dev_alloc(c, &d.dbg, 4096));
     c->plan_cap = 1 << 16;
     TRY(dev_alloc(c, &c->plan_dev, c->plan_cap));
     TRY(dev_alloc(c, &c->pbase_dev, 4));
@@ -476,6 +483,7 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     if (hipHostMalloc((void **)&c->plan_pin, sizeof(bnr_plan_entry) * c->plan_cap) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipHostMalloc failed"); }
     if (hipHostMalloc((void **)&c->counters_host, sizeof(long long) * 16) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipHostMalloc failed"); }
     d.plan = c->plan_dev;
+    if (hipDeviceSynchronize() != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipDeviceSynchronize failed"); }   // every upload and fill above has landed, on whatever stream it ran
     TRY(sync_dev(c));
     TRY(check_launch("chain_build"));                    // the index-map / task-map copies above only NOTE a failure: report it here, not in somebody's later call
 #undef TRY
@@ -521,7 +529,7 @@ static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape)
     HIPCHK(hipStreamCreateWithFlags(&x.stream2, hipStreamNonBlocking));
 #ifdef BNR_EXPERIMENTS
     HIPCHK(hipMalloc((void **)&x.gctl, sizeof(unsigned) * 8 * BNR_GQ_WORDS));
-    HIPCHK(hipMemset(x.gctl, 0, sizeof(unsigned) * 8 * BNR_GQ_WORDS));
+    HIPCHK(hipMemsetAsync(x.gctl, 0, sizeof(unsigned) * 8 * BNR_GQ_WORDS, x.stream));
 #endif
     HIPCHK(hipMalloc((void **)&x.cds, sizeof(bnr_dev) * nb));
     HIPCHK(hipHostMalloc((void **)&x.cds_pin, sizeof(bnr_dev) * nb));
@@ -676,9 +684,21 @@ static bool pipelined(const bnr_exec &x)
 // two panels per launch with the K = 128 trailing update (variant 3) where the trailing update is bandwidth-bound: n_pad >= 1024
 // (n = 2000 one chain 424 -> 448 it/s, n = 1000 eight chains 5.49 -> 5.88 k it/s; at n = 500 it is a draw and the one-panel launches stay)
 static bool two_panel_default(const bnr_exec &x) { return x.shape->n_pad >= 1024; }
+// the data-flow factorization (k_chol_df: one launch, one chain per XCD, blocks resident in registers): n_pad <= 512, groups of up to 8
+// (opt-in, experiments build only: bitwise the same factor, measured slower -- profiles/round4_experiments_notes.txt, F)
+static bool dataflow(const bnr_exec &x)
+{
+#ifdef BNR_EXPERIMENTS
+    if (x.shape->n_pad > 512 || x.nb > 8 || left_looking(x)) return false;
+    return x.factor_variant == 4;
+#else
+    (void)x; return false;
+#endif
+}
 // the one-panel right-looking factorization (k_chol_step) is the one that runs, and its first launch takes over k_gram_reduce's work
 static bool reduce_in_chol(const bnr_exec &x)
 {
+    if (dataflow(x)) return true;                        // (k_chol_df sums the partial tiles at the first touch of every block: no reduction pass at all)
     const bool one_panel = x.factor_variant == 0 || (x.factor_variant < 0 && !two_panel_default(x));
     return one_panel && x.fuse_reduce != 0;
 }
@@ -828,7 +848,8 @@ static int build_qlist(bnr_exec &x)
     HIPCHK(hipSetDevice(x.device));
     if (x.qlist) { HIPCHK(hipStreamSynchronize(x.stream)); (void)hipFree(x.qlist); x.qlist = nullptr; }
     HIPCHK(hipMalloc((void **)&x.qlist, sizeof(bnr_qent) * std::max<size_t>(flat.size(), 1)));
-    HIPCHK(hipMemcpy(x.qlist, flat.data(), sizeof(bnr_qent) * flat.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(x.qlist, flat.data(), sizeof(bnr_qent) * flat.size(), hipMemcpyHostToDevice, x.stream));
+    HIPCHK(hipStreamSynchronize(x.stream));
     x.qW = std::max(1, std::min(BNR_GQ_WORDS - 65, x.ncu / 8 - 4 * __builtin_popcount((unsigned)x.resv_mask)));   // seats = CUs of an XCD the Gram may use
     x.q_for_mask = x.resv_mask;
     return BNR_OK;
@@ -846,6 +867,9 @@ static void launch_rhs(bnr_exec &x, int s) { BNR_LAUNCH(k_rhs, dim3(x.shape->n_p
 static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
 {
     const int nbk = x.shape->n_pad / BNR_NB;
+#ifdef BNR_EXPERIMENTS
+    if (dataflow(x)) { BNR_LAUNCH(k_chol_df, dim3(8 * BNR_DF_WG), dim3(256), 0, st, x, s, x.nb); return; }
+#endif
     if (x.factor_variant == 2 || x.factor_variant == 3 || (x.factor_variant < 0 && two_panel_default(x))) {
         // two panels per launch (k_chol_step2): half the launches on the critical path, the same arithmetic; variant 3 (the choice for
         // large n): the whole trailing matrix is read and written at every other launch only, with K = 128
@@ -915,7 +939,7 @@ static void launch_backproj(bnr_exec &x, int s, int flags)
     BNR_LAUNCH(k_backproj, dim3(round_up(x.shape->nblk_bp, 8) * x.nb), dim3(256), lds, x.stream, x, s, flags, x.nb, nslot);
 }
 static void launch_tail(bnr_exec &x, int s, int mask, int xg_src)
-{ BNR_LAUNCH(k_tail, dim3(1, 1, x.nb), dim3(1024), (size_t)x.shape->R * x.shape->V * sizeof(double), x.stream, x, s, mask, xg_src); }
+{ BNR_LAUNCH(k_tail, dim3(1, 1, x.nb), dim3(BNR_TAIL_THREADS), (size_t)x.shape->R * x.shape->V * sizeof(double), x.stream, x, s, mask, xg_src); }
 // The scalar tail of sweep s with everything it needs: with split_sums the per-block partial sums of update_theta! / update_Lambda!
 // (gibbs.jl:476, 603-605) are not computed by the back-projection on the critical chain but by a launch of their own in front of the tail --
 // the same kernel with flags = 4, the same sums in the same order.
@@ -1538,11 +1562,11 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
     }
     if (!strcmp(name, "factor_variant")) {
 #ifdef BNR_EXPERIMENTS
-        const bool ok = value >= -1 && value <= 3;
+        const bool ok = value >= -1 && value <= 4;
 #else
         const bool ok = value >= -1 && value <= 3 && value != 1;
 #endif
-        if (!ok) return fail(BNR_ERR_BAD_ARG, "factor_variant must be -1 (auto), 0 (right-looking), 2 (right-looking, two panels per launch) or 3 (2 with the K = 128 trailing update); 1 (left-looking) is an experiment (-DBNR_EXPERIMENTS)");
+        if (!ok) return fail(BNR_ERR_BAD_ARG, "factor_variant must be -1 (auto), 0 (right-looking), 2 (right-looking, two panels per launch) or 3 (2 with the K = 128 trailing update); 1 (left-looking) and 4 (data-flow, one launch) are experiments (-DBNR_EXPERIMENTS)");
         x.factor_variant = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "graph_k")) { if (value < 1 || value > 256) return fail(BNR_ERR_BAD_ARG, "graph_k out of range"); x.graph_k = (int)value; drop_graph(x); return BNR_OK; }
@@ -1575,7 +1599,7 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
             HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
             x.lstreams.push_back(st);
         }
-        if (lin && !x.lflags) { HIPCHK(hipMalloc((void **)&x.lflags, sizeof(unsigned long long) * 64)); HIPCHK(hipMemset(x.lflags, 0, sizeof(unsigned long long) * 64)); }
+        if (lin && !x.lflags) { HIPCHK(hipMalloc((void **)&x.lflags, sizeof(unsigned long long) * 64)); HIPCHK(hipMemsetAsync(x.lflags, 0, sizeof(unsigned long long) * 64, x.stream)); }
         x.lin = lin; x.lin_merge = merge;
         return BNR_OK;
     }
@@ -1616,7 +1640,8 @@ static int prime_graphs(bnr_exec &x, const std::vector<bnr_chain *> &members)
     std::vector<std::vector<long long>> saved;
     int rc = prime_graphs_inner(x, members, saved);
     for (size_t i = 0; i < saved.size() && i < members.size(); ++i) {
-        if (hipMemcpy(members[i]->d.counters, saved[i].data(), sizeof(long long) * 16, hipMemcpyHostToDevice) != hipSuccess && !rc) rc = fail(BNR_ERR_HIP, "restoring the event counters failed");
+        if ((hipMemcpyAsync(members[i]->d.counters, saved[i].data(), sizeof(long long) * 16, hipMemcpyHostToDevice, x.stream) != hipSuccess || hipStreamSynchronize(x.stream) != hipSuccess) && !rc)
+            rc = fail(BNR_ERR_HIP, "restoring the event counters failed");
         members[i]->carried_row = -1;
     }
     return rc;
@@ -1632,7 +1657,8 @@ static int prime_graphs_inner(bnr_exec &x, const std::vector<bnr_chain *> &membe
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(c->x.stream));
         saved.emplace_back(16);
-        HIPCHK(hipMemcpy(saved.back().data(), c->d.counters, sizeof(long long) * 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(saved.back().data(), c->d.counters, sizeof(long long) * 16, hipMemcpyDeviceToHost, c->x.stream));
+        HIPCHK(hipStreamSynchronize(c->x.stream));
         const int src = c->next_row - 2, scr0 = c->d.tot;
         rc = refresh_carried(c, src);                       // uses plan slot 0 itself: before the plan below is written
         if (rc) return rc;
@@ -1951,7 +1977,8 @@ int bnr_chain_resize(bnr_chain *c, int32_t new_tot)
     int rc = alloc_trace(c, new_tot, &nt);
     if (rc) return rc;
     size_t keep = (size_t)std::min(new_tot, d.tot) * d.rowlen * sizeof(double);   // the hidden scratch row holds nothing between calls
-    HIPCHK(hipMemcpy(nt, old, keep, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpyAsync(nt, old, keep, hipMemcpyDeviceToDevice, c->x.stream));   // behind the zero fill of the new table, on the same stream
+    HIPCHK(hipStreamSynchronize(c->x.stream));
     (void)hipFree(old);
     d.trace = nt; d.tot = new_tot;
     drop_graph(c->x);
@@ -2334,7 +2361,7 @@ int bnr_chain_counters(bnr_chain *c, int64_t out[8])
 
 int bnr_chain_debug_read(bnr_chain *c, uint64_t *out, int32_t count)
 {
-    if (!c || !out || count < 0 || count > 1024) return fail(BNR_ERR_BAD_ARG, "bad argument");
+    if (!c || !out || count < 0 || count > 4096) return fail(BNR_ERR_BAD_ARG, "bad argument");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy(out, c->d.dbg, sizeof(uint64_t) * count, hipMemcpyDeviceToHost));
     return BNR_OK;

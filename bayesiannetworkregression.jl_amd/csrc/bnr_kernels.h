@@ -65,6 +65,8 @@ struct bnr_dev {
     unsigned int *gprog;         // Gram progress: [tc] = finished (tile, K slice) tasks of tile column tc of the running sweep (read by
                                  // k_chol_ll, zeroed by its last launch); [ntile] = task queue head of k_gram8p; [ntile + 1] = sticky "a gate timed out"
     const int *gmapc;            // k_gram8p: task list in tile-COLUMN order (tile | ks << 16): the factorization consumes G column by column
+    unsigned int *dfctl;         // (experiments build only, else null) data-flow factorization (k_chol_df): [0] epoch (one more per Gram launch), [1] XCDs its workgroups ran on (bit mask),
+                                 // [32 + 32 q + block row] = epoch when block (block row, q) of the factor is in E
 };
 
 // How a sweep kernel finds its chain.  One chain: the struct travels by value in the kernel arguments (no dependent
@@ -86,7 +88,7 @@ __device__ __forceinline__ bnr_dev bnr_globalized(const bnr_dev *src)
     BNR_GLOBAL_PTR(pbase); BNR_GLOBAL_PTR(Wbuf); BNR_GLOBAL_PTR(sz); BNR_GLOBAL_PTR(PW); BNR_GLOBAL_PTR(PA); BNR_GLOBAL_PTR(PG);
     BNR_GLOBAL_PTR(Gpart); BNR_GLOBAL_PTR(E); BNR_GLOBAL_PTR(gmap); BNR_GLOBAL_PTR(a3); BNR_GLOBAL_PTR(xw); BNR_GLOBAL_PTR(a4);
     BNR_GLOBAL_PTR(res); BNR_GLOBAL_PTR(xg); BNR_GLOBAL_PTR(bw); BNR_GLOBAL_PTR(wv); BNR_GLOBAL_PTR(scal); BNR_GLOBAL_PTR(Minv);
-    BNR_GLOBAL_PTR(Psum); BNR_GLOBAL_PTR(counters); BNR_GLOBAL_PTR(dbg); BNR_GLOBAL_PTR(stamp); BNR_GLOBAL_PTR(gprog); BNR_GLOBAL_PTR(gmapc);
+    BNR_GLOBAL_PTR(Psum); BNR_GLOBAL_PTR(counters); BNR_GLOBAL_PTR(dbg); BNR_GLOBAL_PTR(stamp); BNR_GLOBAL_PTR(gprog); BNR_GLOBAL_PTR(gmapc); BNR_GLOBAL_PTR(dfctl);
     return d;
 }
 struct bnr_one {
@@ -107,8 +109,12 @@ struct bnr_many {
 // the previous row forward so that the critical chain keeps working on sane numbers) -- what the panel steps cost without company
 __device__ int bnr_exp_flags = 0;
 #define BNR_EXP_SKIP_SCALAR() (__builtin_amdgcn_readfirstlane(bnr_exp_flags) & 1)
+// bits 8..15 = N > 0: the panel steps p >= N of the factorization return at once (results are then wrong) -- how short would the sweep be if the
+// factorization were that much faster, i.e. where does the scalar branch take over as the critical chain?
+#define BNR_EXP_SKIP_CHOL(p) (((__builtin_amdgcn_readfirstlane(bnr_exp_flags) >> 8) & 255) != 0 && (p) >= ((__builtin_amdgcn_readfirstlane(bnr_exp_flags) >> 8) & 255))
 #else
 #define BNR_EXP_SKIP_SCALAR() 0
+#define BNR_EXP_SKIP_CHOL(p) 0
 #endif
 enum { ROW_TAU2 = 0, ROW_THETA = 1, ROW_DELTA = 2, ROW_MU = 3 };
 enum { SC_RR = 0, SC_SIGQ = 1, SC_TAU = 2, SC_TAU2N = 3, SC_TAU2N_IT = 4 };   // TAU2N: tau2 pre-drawn by k_tail for iteration id TAU2N_IT
@@ -164,6 +170,17 @@ __device__ __forceinline__ double block_sum(double v, double *sh /* >= blockDim/
     return s;
 }
 
+// wave-uniform values pinned to scalar registers (v_readfirstlane): inside a task loop the compiler cannot use scalar loads for what it
+// reads after the first store of the kernel, and a uniform value left in a vector register drags the address arithmetic built on it there too
+__device__ __forceinline__ int bnr_sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double bnr_sgpr_f64(double x) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x))); }
+template <class T>
+__device__ __forceinline__ T *bnr_sgpr_global(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (T *)(__attribute__((address_space(1))) void *)(((unsigned long long)hi << 32) | lo);
+}
 // ---- single-wave small dense routines on LDS matrices (column-major R x R), blockDim.x == 64 or wave 0 of a block.
 // `sync` must be a barrier valid for the participating threads: we always call these from code paths where the
 // WHOLE block executes them (other waves just take part in the barriers).
@@ -521,6 +538,14 @@ typedef double bnr_d2 __attribute__((ext_vector_type(2)));
 // first read of the column).  k_gram / k_gram8 are consumed after the kernel boundary: one relaxed atomic, no fence.
 // Only the opt-in left-looking / pipelined factorization reads the counts (builds with -DBNR_EXPERIMENTS): the default library does not
 // count at all (round 3 did, on every launch: one agent-scope atomic per workgroup on 8 words per chain).
+#ifdef BNR_EXPERIMENTS
+// One Gram launch = one epoch of the data-flow factorization that follows it (k_chol_df tags its hand-over flags with it: nothing has to be
+// zeroed between two sweeps, and a flag of an earlier factorization can never be mistaken for one of this).  Bumped by the workgroup of task slot 0.
+__device__ __forceinline__ void bnr_gram_epoch(const bnr_dev &cd, int gslot)
+{
+    if (gslot == 0 && threadIdx.x == 0) cd.dfctl[0] += 1u;
+}
+#endif
 __device__ __forceinline__ void bnr_gram_count(const bnr_dev &cd, int tj)
 {
 #ifdef BNR_EXPERIMENTS
@@ -713,6 +738,9 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
     int tj = t - ti * (ti + 1) / 2;
     bnr_gram16_task<KG, false>(bnr_geom_of(cd), Sp, cd.Gpart, t, ti, tj, ks, sred);
     bnr_gram_count(cd, tj);
+#ifdef BNR_EXPERIMENTS
+    bnr_gram_epoch(cd, gslot);
+#endif
 }
 
 // k_gram8: the same Gram, the same task map, the same summation order per element (bitwise the same partial tiles) -- for SIX
@@ -859,6 +887,9 @@ __global__ __launch_bounds__(512, 6) void k_gram8(const SRC chain_src, int s, in
     int tj = t - ti * (ti + 1) / 2;
     bnr_gram8_task<false>(bnr_geom_of(cd), Sp, cd.Gpart, t, ti, tj, ks, sred);
     bnr_gram_count(cd, tj);
+#ifdef BNR_EXPERIMENTS
+    bnr_gram_epoch(cd, gslot);
+#endif
 }
 
 // E = extended matrix of the factorization, (2 n_pad + 32) x n_pad, column-major, leading dimension ldE:
@@ -1206,6 +1237,7 @@ template <class SRC>
 __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p, int s, int tpw, int spw, int fuse0)
 {
     BNR_CRITICAL_PATH();
+    if (BNR_EXP_SKIP_CHOL(p)) return;
     const bnr_dev &cd = chain_src.get_x();               // grid = (chains, workgroups): blockIdx.x = chain, blockIdx.y = workgroup
     __shared__ bnr_panel_lds sh;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nbk = cd.n_pad / BNR_NB;
@@ -1694,6 +1726,14 @@ __global__ __launch_bounds__(256) void k_solve_w(const SRC chain_src)
     BNR_CRITICAL_PATH();
     const bnr_dev &cd = chain_src.get();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, np = cd.n_pad;
+#ifdef BNR_EXPERIMENTS
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // k_chol_df hands data over through ONE XCD's L2: its workgroups must all have run on the same XCD (they report it here)
+        const unsigned m = cd.dfctl[1];
+        if (m & (m - 1u)) atomicAdd((unsigned long long *)&cd.counters[8], 1ull);
+        cd.dfctl[1] = 0u;
+    }
+#endif
     const int c = blockIdx.x * 4 + wave;
     const size_t ld = bnr_ldE(np);
     const double *col = cd.E + (size_t)np + ld * (size_t)c;
@@ -1927,8 +1967,12 @@ __device__ inline void wave_tri_inverse(const double *A, double *T, int R, int l
     bnr_wsync();
 }
 
+#ifndef BNR_TAIL_THREADS
+#define BNR_TAIL_THREADS 512   // 8 wavefronts: the seven role waves of phase 3 + one; two per SIMD, so the kernel may use 256 vector registers (no spills: with
+                               // 1024 threads it had 128 and spilled) and fits a CU beside other resident workgroups instead of needing an empty one
+#endif
 template <class SRC>
-__global__ __launch_bounds__(1024) void k_tail(const SRC chain_src, int s, int mask, int xg_src)
+__global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, int s, int mask, int xg_src)
 {
     const bnr_dev &cd = chain_src.get();
     extern __shared__ double su[];               // R x V: u of this row (staged once, used by Psi and by the q pass)
@@ -1940,10 +1984,12 @@ __global__ __launch_bounds__(1024) void k_tail(const SRC chain_src, int s, int m
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     if (P.wrap & 2) return;                      // placeholder entry in front of the first sweep of a run
     if (BNR_EXP_SKIP_SCALAR() && mask == 1023) return;
-    double *row = cd.trace + (size_t)P.row * cd.rowlen;
-    const double *prev = cd.trace + (size_t)P.prev * cd.rowlen;
-    const int R = cd.R, V = cd.V, q = cd.q, n = cd.n, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-    const double tau2 = row[ROW_TAU2];
+    // (the row pointers are the same for the whole workgroup: pinned to scalar registers -- as vector values they lived through the whole
+    // kernel, and the register allocator spilled them and the thread id around the inlined samplers: 32 bytes of scratch per lane in round 3)
+    double *row = bnr_sgpr_global(cd.trace + (size_t)P.row * cd.rowlen);
+    const double *prev = bnr_sgpr_global((const double *)(cd.trace + (size_t)P.prev * cd.rowlen));
+    const int R = cd.R, V = cd.V, q = cd.q, n = cd.n, tid = threadIdx.x, wave = bnr_sgpr((int)(threadIdx.x >> 6)), lane = tid & 63, nw = blockDim.x >> 6;
+    const double tau2 = bnr_sgpr_f64(row[ROW_TAU2]);
     int cap = 0;
 #ifdef BNR_STAMPS
 #define BNR_TSTAMP(slot) do { if (tid == 0) cd.dbg[256 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -2004,6 +2050,8 @@ __global__ __launch_bounds__(1024) void k_tail(const SRC chain_src, int s, int m
         sxi = 0.0; snz = 0.0; sres = 0.0;
         for (int w = 0; w < nw; ++w) { sxi += sred[w]; snz += sred[16 + w]; sres += sred[32 + w]; }
     }
+    // (the same in every lane from here on: scalar registers -- the samplers inlined below need the vector ones)
+    sxi = bnr_sgpr_f64(sxi); snz = bnr_sgpr_f64(snz); sres = bnr_sgpr_f64(sres);
     const double df = cd.nu + snz;
     BNR_TSTAMP(2);
     // ---- phase 3: independent work on separate wavefronts
@@ -2061,6 +2109,7 @@ __global__ __launch_bounds__(1024) void k_tail(const SRC chain_src, int s, int m
         for (int j = lane; j < R; j += 64) sBm[j + R * j] = sqrt(2.0 * bnr_gamma(cd.seed, 0.5 * (df - j), P.it, SITE_M_CHI, (uint32_t)j, &cap));
     }
     if (wave == 5 && (mask & 4)) {                                               // Bartlett strictly lower: normals; upper: 0
+#pragma unroll 1
         for (int idx = lane; idx < R * R; idx += 64) {
             int i = idx % R, j = idx / R;
             if (i > j) sBm[idx] = bnr_normal(cd.seed, P.it, SITE_M_N, (uint32_t)(i * R + j), 0);

@@ -237,7 +237,8 @@ int bnr_debug_set_exp(int32_t device, int32_t flags);
  *   "profiling" 1: record HIP events around every k_gram launch (forces eager launches), see bnr_chain_last_timing
  *   "factor_variant" -1 (default): chosen by size -- 0 below n_pad = 1024, 3 from there on; 0: right-looking factorization, one
  *               32-column panel per launch (k_gram_reduce + k_chol_step); 2: right-looking, two panels per launch (k_chol_step2); 3: 2 with
- *               the whole trailing matrix updated at every other launch only (K = 128); (1: left-looking k_chol_ll, -DBNR_EXPERIMENTS only)
+ *               the whole trailing matrix updated at every other launch only (K = 128); (1: left-looking k_chol_ll, 4: data-flow k_chol_df --
+ *               -DBNR_EXPERIMENTS only)
  *   "fuse_reduce" 1 / -1 (default): launch 0 of the one-panel factorization also sums the Gram's K-split partial tiles (no k_gram_reduce
  *               launch); 0: separate reduction pass
  *   "group_xpass" -1 (default): a lockstep group whose members share the device copy of X (bnr_chain_create_like) runs ONE X pass

@@ -1,10 +1,12 @@
 # BNRHip.jl -- thin Julia shim over libbnr_hip.so (include/bnr_hip.h).
-# SPDX-License-Identifier: GPL-2.0-or-later.  The schedule arithmetic of `generate_samples!` below (num2move, first_index, the
-# messages) restates BayesianNetworkRegression.jl src/gibbs.jl:955-1013 (GPL-2.0, Ozminkowski & Solis-Lemus) so that this
-# module is a drop-in for that function; everything else is `ccall` glue written for this repository.
+# SPDX-License-Identifier: GPL-2.0-or-later.  The schedule arithmetic of `generate_samples!` / `generate_samples_dbl!` below (num2move,
+# first_index, table sizes, the messages) and the layout of `Fit!`'s parameters.log restate BayesianNetworkRegression.jl
+# src/gibbs.jl:729-746, 955-1013, 1119-1190 (GPL-2.0, Ozminkowski & Solis-Lemus) so that this module is a drop-in for those
+# functions; everything else is `ccall` glue written for this repository.
 #
-# Drop-in for the Gibbs hot path of BayesianNetworkRegression.jl: `generate_samples!` with the reference's argument meaning
-# (src/gibbs.jl:897-1020, including the PSRF-driven top-up rounds) returning the reference's own
+# Drop-in for the Gibbs hot path of BayesianNetworkRegression.jl: `Fit!` (src/gibbs.jl:725-751: parameters.log, scheme dispatch),
+# `generate_samples!` (src/gibbs.jl:897-1020, including the PSRF-driven top-up rounds) and `generate_samples_dbl!` (the "doubling"
+# scheme, src/gibbs.jl:1051-1198) with the reference's keyword names, defaults and argument meaning, returning the reference's own
 # `Results(state::Table, rhatÎ¾::Table, rhatÎ³::Table, burn_in, sampled)` (src/gibbs.jl:23-29), so `Summary` and `show` of the
 # package work unchanged.  No sampling logic lives here: every step is a `ccall`; what remains is the reference's schedule
 # arithmetic (num2move, first_index), kept line for line with gibbs.jl:962-1013.
@@ -18,8 +20,8 @@
 # the Python/ctypes mirror (bayesiannetworkregression.jl_amd/_capi.py, api.py) in tests/.
 module BNRHip
 
-using TypedTables, Random
-import BayesianNetworkRegression: Results
+using TypedTables, Random, Dates
+import BayesianNetworkRegression: Results, citation
 
 const LIB = get(ENV, "BNR_HIP_LIB", joinpath(@__DIR__, "..", "bayesiannetworkregression.jl_amd", "libbnr_hip.so"))
 
@@ -228,6 +230,99 @@ function generate_samples!(X, y, R; Î·=1.01, Î¶=1.0, Î¹=1.0, aÎ”=1.0, bÎ”=1.0, Î
     end
     state = 1 in ids ? fetch!(new_table(tot_save, V, R), chains[1]) : nothing    # only chain 1's trace is returned (gibbs.jl:788)
     Results(state, Table(Î¾ = rx), Table(Î³ = rg), stt, nsamp)
+end
+
+# generate_samples_dbl!(X, y, R; ...) (gibbs.jl:1051-1198): the "doubling" scheme -- a first pass of mingen iterations (half burn-in), then,
+# while max Rhat > psrf_cutoff and fewer than maxgen iterations were generated, rounds that keep every sample so far, grow the table by
+# mingen/2 rows (the reference allocates a new table and block-copies the tail, :1164-1172; here: move_rows! + resize_table! on the
+# device) and run on from row num2move + 1.
+function generate_samples_dbl!(X, y, R; Î·=1.01, Î¶=1.0, Î¹=1.0, aÎ”=1.0, bÎ”=1.0, Î½=10, mingen=10000, maxgen=100000, psrf_cutoff=1.01,
+                               x_transform=true, suppress_timer=false, num_chains=2, seed=nothing, purge_burn=nothing,
+                               device=0, comm::Union{Comm,Nothing}=nothing, tick=nothing)
+    if Î½ == R
+        println("Warning: Î½==R may give poor accuracy. Consider increasing Î½")                      # :1057-1059
+    end
+    nburn = convert(Int64, round(mingen / 2))                                                      # :1061-1062
+    nsamp = mingen - nburn
+    V = x_transform ? size(X[1], 1) : Int64((-1 + sqrt(1 + 8 * size(X, 2))) / 2)
+    q = floor(Int, V * (V + 1) / 2)
+    total = nburn + nsamp
+    prog_freq = 1000 >= nburn ? 10 : 1000
+    if !isnothing(purge_burn) && (purge_burn < nburn) && purge_burn != 0
+        if nburn % purge_burn != 0
+            purge_burn = purge_burn - (nburn % purge_burn)
+        end
+    else
+        purge_burn = nothing
+    end
+    tot_save = isnothing(purge_burn) ? total : nsamp + purge_burn
+    seed = isnothing(seed) ? rand(1:55555) : seed
+    rank, world = comm === nothing ? (0, 1) : (comm.rank, comm.world)
+    ids = [c for c in 1:num_chains if (c - 1) % world == rank]
+    yv = Vector{Float64}(y)
+    chains = Chain[]
+    for c in ids
+        push!(chains, isempty(chains) ? Chain(X, yv, R, tot_save, seed, c; x_transform, Î·, Î¶, Î¹, aÎ”, bÎ”, Î½, device) :
+                                        chain_like(chains[1], seed, c, tot_save))
+    end
+    foreach(init_prior!, chains)
+    runner = length(chains) > 1 ? Group(chains) : (isempty(chains) ? nothing : chains[1])
+    mytick = 1 in ids ? tick : nothing
+    isnothing(runner) || run!(runner, 2, nburn, total, purge_burn; prog_freq, tick = mytick)
+    tot_generated = nburn + nsamp
+    tot_samples = nsamp
+    stt = isnothing(purge_burn) ? nburn : purge_burn
+    rx, rg = psrf(chains, num_chains, comm, stt, nsamp, V, q)
+    println(stderr, tot_generated, " samples generated. Max PSRF XI: ", round(maximum(rx), digits=3), ". Max PSRF Gamma: ", round(maximum(rg), digits=3))
+    bad(a, b) = maximum(a) > psrf_cutoff || maximum(b) > psrf_cutoff || isnan(maximum(a)) || isnan(maximum(b))
+    while bad(rx, rg) && tot_generated < maxgen                                                    # :1119
+        halfburn = convert(Int64, round(mingen / 2))
+        num2move = tot_samples                                                                     # :1143
+        tot_samples = tot_samples + halfburn
+        nsamp = tot_samples
+        tot_sze = tot_save
+        tot_save = tot_samples + halfburn
+        println(stderr, "num2move: ", num2move, " nburn: ", nburn, " nsamp: ", nsamp, " tot_save: ", tot_save, " first_index: ", num2move + 1)
+        for ch in chains                                                                           # new table + copy_table! of the tail (:1164-1172)
+            move_rows!(ch, 1, tot_sze - num2move + 1, num2move)
+            resize_table!(ch, tot_save)
+        end
+        isnothing(runner) || run!(runner, num2move + 1, 0, tot_save, purge_burn; prog_freq, tick = mytick)   # run! :1176-1178
+        tot_generated = tot_generated + mingen
+        rx, rg = psrf(chains, num_chains, comm, stt, nsamp, V, q)
+        println(stderr, tot_generated, " samples generated. Max PSRF XI: ", round(maximum(rx), digits=3), ". Max PSRF Gamma: ", round(maximum(rg), digits=3))
+    end
+    state = 1 in ids ? fetch!(new_table(tot_save, V, R), chains[1]) : nothing
+    Results(state, Table(Î¾ = rx), Table(Î³ = rg), stt, nsamp)
+end
+
+# Fit!(X, y, R; ...) (gibbs.jl:725-751): writes parameters.log (timestamp, the package's citation, every keyword, the seed -- rank 0 only
+# when the fit spans several ranks), draws the seed when none is given, then the doubling scheme if mingen > 0 and maxgen > 0, else the
+# traditional one with maxburn = nburn + nsamples.  `V` is accepted and ignored, as in the reference.
+function Fit!(X, y, R; Î·=1.01, V=30, Î¶=1.0, Î¹=1.0, aÎ”=1.0, bÎ”=1.0, Î½=10, nburn=30000, nsamples=20000, mingen=0, maxgen=0,
+              psrf_cutoff=1.01, x_transform=true, suppress_timer=false, num_chains=2, seed=nothing, purge_burn=nothing,
+              filename="parameters.log", device=0, comm::Union{Comm,Nothing}=nothing, tick=nothing)
+    seed = isnothing(seed) ? rand(1:55555) : seed                # (with several ranks the caller passes ONE seed to all of them, see generate_samples!)
+    if comm === nothing || comm.rank == 0
+        open(filename, "w") do logfile
+            write(logfile, "BayesianNetworkRegression.jl Fit! function\n")
+            write(logfile, Dates.format(Dates.now(), "yyyy-mm-dd H:M:S.s") * "\n")
+            write(logfile, citation(returnstring=true))
+            write(logfile, "\n\nParameters:\n")
+            str = "R=$R, Î·=$Î·, Î¶=$Î¶, Î¹=$Î¹, aÎ”=$aÎ”, bÎ”=$bÎ”, Î½=$Î½, nburn=$nburn, nsamples=$nsamples, \n"
+            str *= "mingen=$mingen, maxgen=$maxgen, psrf_cutoff=$psrf_cutoff, \n"
+            str *= "x_transform=$x_transform, suppress_timer=$suppress_timer, num_chains=$num_chains, purge_burn=$purge_burn \n"
+            str *= "seed=$seed"
+            write(logfile, str)
+        end
+    end
+    if (mingen > 0) && (maxgen > 0)
+        generate_samples_dbl!(X, y, R; Î·, Î¶, Î¹, aÎ”, bÎ”, Î½, mingen, maxgen, psrf_cutoff, x_transform, suppress_timer, num_chains, seed, purge_burn,
+                              device, comm, tick)
+    else
+        generate_samples!(X, y, R; Î·, Î¶, Î¹, aÎ”, bÎ”, Î½, nburn, nsamp = nsamples, maxburn = nburn + nsamples, psrf_cutoff, x_transform,
+                          suppress_timer, num_chains, seed, purge_burn, device, comm, tick)
+    end
 end
 
 end # module
