@@ -1015,7 +1015,18 @@ __global__ void k_zero_words(unsigned *p, int n) { for (int i = threadIdx.x; i <
 //   needs and applies the update.  Nobody waits for anything but panels of lower index: with all workgroups resident (64 per chain, two per CU:
 //   512 of 256 threads at most) the launch always ends; a wait that outlasts BNR_DF_TIMEOUT_US gives up and raises the status.
 //   grid = 8 x 64 workgroups of 256 threads; lockstep groups of up to 8 chains (more: k_chol_step).
-#define BNR_DF_WG 64
+#ifndef BNR_DF_NG
+#define BNR_DF_NG 4                    // column groups: workgroup (slot, group) owns slot `slot` of the columns group, group + NG, ...: 16 / NG blocks.  4: 64 workgroups of 4 blocks per
+#endif                                 // chain, two per CU (171 VGPRs each: nothing of the scalar branch fits beside them); 2: 32 workgroups of 8 blocks, ONE per CU (95 KB of LDS), one wave per SIMD
+#ifndef BNR_DF_PRIO
+#define BNR_DF_PRIO 1                  // 1: s_setprio 3 throughout (like the other kernels of the critical chain); 2: priority 0 while polling; 0: never raised
+#endif
+#ifndef BNR_DF_SLEEP
+#define BNR_DF_SLEEP 1
+#endif
+#define BNR_DF_KB (16 / BNR_DF_NG)
+#define BNR_DF_WG (16 * BNR_DF_NG)
+#define BNR_DF_LDS (BNR_DF_KB * BNR_NB * BNR_LP * sizeof(double))
 #define BNR_DF_TIMEOUT_US 200000
 __device__ __forceinline__ double bnr_ld_l2(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // the wave's 16 x 16 tile (columns mt, rows nt) of a 32 x 32 block kept in LDS (row + BNR_LP * column, like the sweep's staging area)
@@ -1073,22 +1084,33 @@ __device__ __forceinline__ bool bnr_df_wait2(const unsigned int *f0, const unsig
     unsigned a = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a == epoch && b == epoch) return true;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#if BNR_DF_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);                       // a polling wave must not outrank the neighbours' working waves
+#endif
+    bool ok = false;
     for (;;) {
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(BNR_DF_SLEEP);
         a = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); b = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a == epoch && b == epoch) return true;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 100ull * BNR_DF_TIMEOUT_US) return false;
+        if (a == epoch && b == epoch) { ok = true; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 100ull * BNR_DF_TIMEOUT_US) break;
     }
+#if BNR_DF_PRIO == 2
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    return ok;
 }
 template <class SRC>
 __global__ __launch_bounds__(256) void k_chol_df(const SRC chain_src, int s, int nchains)
 {
+#if BNR_DF_PRIO
     BNR_CRITICAL_PATH();
+#endif
     const int chain = blockIdx.x & 7, w = blockIdx.x >> 3;
     if (chain >= nchains) return;
     const bnr_dev &cd = chain_src.at(chain);
     __shared__ bnr_panel_lds sh;
-    __shared__ double sDc[4][BNR_NB * BNR_LP];            // my copies of the diagonal blocks of my four columns
+    extern __shared__ double sDc_[];                      // my copies of the diagonal blocks of my columns: BNR_DF_KB x (BNR_NB * BNR_LP)
+    double (*sDc)[BNR_NB * BNR_LP] = (double (*)[BNR_NB * BNR_LP])sDc_;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nbk = cd.n_pad / BNR_NB;
     const int slot = w & 15, grp = w >> 4;
     if (slot >= nbk) return;
@@ -1100,13 +1122,16 @@ __global__ __launch_bounds__(256) void k_chol_df(const SRC chain_src, int s, int
     if (tid == 0) {
         unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
         __hip_atomic_fetch_or(&cd.dfctl[1], 1u << (v & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef BNR_STAMPS
+        if (chain == 0) { unsigned h; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h)); cd.dbg[1000 + w] = __builtin_amdgcn_s_memrealtime(); cd.dbg[1200 + w] = h; }
+#endif
     }
-    // my blocks: column j_k = grp + 4 k; block row: matrix row j + 1 + slot while there are any, then identity row slot - (nbk - 1 - j)
-    bnr_d4 cB[4];
-    int brow[4];                                         // block row in E (matrix rows 0 .. nbk-1, identity rows nbk ..); -1: no block
+    // my blocks: column j_k = grp + NG k; block row: matrix row j + 1 + slot while there are any, then identity row slot - (nbk - 1 - j)
+    bnr_d4 cB[BNR_DF_KB];
+    int brow[BNR_DF_KB];                                         // block row in E (matrix rows 0 .. nbk-1, identity rows nbk ..); -1: no block
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int j = grp + 4 * k;
+    for (int k = 0; k < BNR_DF_KB; ++k) {
+        const int j = grp + BNR_DF_NG * k;
         brow[k] = -1;
         cB[k] = bnr_d4{0.0, 0.0, 0.0, 0.0};
         if (j < nbk) {
@@ -1141,8 +1166,8 @@ __global__ __launch_bounds__(256) void k_chol_df(const SRC chain_src, int s, int
         for (int pass = 0; pass < 2; ++pass) {
             if (p >= 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int j = grp + 4 * k;
+                for (int k = 0; k < BNR_DF_KB; ++k) {
+                    const int j = grp + BNR_DF_NG * k;
                     if (j <= p || j >= nbk || brow[k] < 0) continue;
                     if ((pass == 0) != (j == p + 1)) continue;
                     // L[j, p] and my block row of panel p (an identity row r has one only from p = r on: before that the update reads zeros)
@@ -1154,14 +1179,15 @@ __global__ __launch_bounds__(256) void k_chol_df(const SRC chain_src, int s, int
                 }
             }
             const int q = p + 1;                                                            // the column that is complete now
-            if (pass == 0 && q < nbk && (q & 3) == grp) {
+            if (pass == 0 && q < nbk && (q % BNR_DF_NG) == grp) {
 #ifdef BNR_STAMPS
                 if (slot == 0 && chain == 0 && tid == 0) { cd.dbg[400 + 8 * q + 4] = __builtin_amdgcn_s_memrealtime(); }
 #endif
-                const int k = q >> 2;
+                const int k = q / BNR_DF_NG;
                 bnr_d4 sB = cB[0];
                 int br = brow[0];
-                if (k == 1) { sB = cB[1]; br = brow[1]; } else if (k == 2) { sB = cB[2]; br = brow[2]; } else if (k == 3) { sB = cB[3]; br = brow[3]; }
+#pragma unroll
+                for (int kk = 1; kk < BNR_DF_KB; ++kk) if (k == kk) { sB = cB[kk]; br = brow[kk]; }
                 if (br >= 0) {
                     double *dst = E + (size_t)(br * BNR_NB) + ld * (size_t)(q * BNR_NB);
                     const bnr_d4 sD = bnr_lds_tile_get(sDc[k], mt, nt, ln, lq);
@@ -1179,6 +1205,9 @@ __global__ __launch_bounds__(256) void k_chol_df(const SRC chain_src, int s, int
             }
         }
     }
+#ifdef BNR_STAMPS
+    if (chain == 0 && tid == 0) cd.dbg[1100 + w] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (bad && tid == 0 && w == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[7], 1ull); }
     if (late && lane == 0) atomicAdd((unsigned long long *)&cd.counters[8], 1ull);       // a hand-over never came: the run fails loudly ("stream ordering violated")
 }

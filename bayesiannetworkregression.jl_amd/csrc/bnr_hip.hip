@@ -154,7 +154,7 @@ static int ensure_lds_attributes(int device)
     const void *fns[] = {(const void *)&k_tail<bnr_one>, (const void *)&k_tail<bnr_many>, (const void *)&k_backproj<bnr_one>,
                          (const void *)&k_backproj<bnr_many>, (const void *)&k_solve_a4<bnr_one>, (const void *)&k_solve_a4<bnr_many>,
 #ifdef BNR_EXPERIMENTS
-                         (const void *)&k_chol_ll<bnr_one>, (const void *)&k_chol_ll<bnr_many>,
+                         (const void *)&k_chol_ll<bnr_one>, (const void *)&k_chol_ll<bnr_many>, (const void *)&k_chol_df<bnr_one>, (const void *)&k_chol_df<bnr_many>,
                          (const void *)&k_gram_gate<bnr_one>, (const void *)&k_gram_gate<bnr_many>, (const void *)&k_backproj_group,
 #endif
                          (const void *)&k_xpass_group};
@@ -868,7 +868,7 @@ static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
 {
     const int nbk = x.shape->n_pad / BNR_NB;
 #ifdef BNR_EXPERIMENTS
-    if (dataflow(x)) { BNR_LAUNCH(k_chol_df, dim3(8 * BNR_DF_WG), dim3(256), 0, st, x, s, x.nb); return; }
+    if (dataflow(x)) { BNR_LAUNCH(k_chol_df, dim3(8 * BNR_DF_WG), dim3(256), BNR_DF_LDS, st, x, s, x.nb); return; }
 #endif
     if (x.factor_variant == 2 || x.factor_variant == 3 || (x.factor_variant < 0 && two_panel_default(x))) {
         // two panels per launch (k_chol_step2): half the launches on the critical path, the same arithmetic; variant 3 (the choice for

@@ -265,6 +265,13 @@ __global__ __launch_bounds__(64) void k_node(const SRC chain_src, int s, int mod
         if (k == 0) { for (int i = lane; i < cd.o_gamma; i += 64) row[i] = prev[i]; if (lane == 0) cd.scal[SC_TAU] = sqrt(prev[ROW_TAU2]); }
         return;
     }
+#ifdef BNR_STAMPS
+    if (lane == 0 && k < 256) {                           // diagnostics: when did this node's wave start / finish its sums / end, and on which XCD
+        unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+        unsigned h; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h));
+        cd.dbg[2000 + 4 * k] = __builtin_amdgcn_s_memrealtime(); cd.dbg[2000 + 4 * k + 3] = (v & 7u) | ((unsigned long long)h << 8);
+    }
+#endif
     int cap = 0;
     double tau2;
     if (mode & 1) {
@@ -331,6 +338,9 @@ __global__ __launch_bounds__(64) void k_node(const SRC chain_src, int s, int mod
     }
     __syncthreads();
 
+#ifdef BNR_STAMPS
+    if (lane == 0 && k < 256) cd.dbg[2000 + 4 * k + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
     double logdetM;
     int fail = 0;
     if (mode & 4) {
@@ -402,6 +412,9 @@ __global__ __launch_bounds__(64) void k_node(const SRC chain_src, int s, int mod
     if (lane < R) row[cd.o_u + lane + R * k] = xi * (mt + z);
     if (lane == 0) row[cd.o_xi + k] = xi;
     if (cap && lane == 0 && k == 0) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
+#ifdef BNR_STAMPS
+    if (lane == 0 && k < 256) cd.dbg[2000 + 4 * k + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ===================================================================================== k_xpass
