@@ -11,8 +11,10 @@
 // Sweep order and what each kernel covers (gibbs.jl:663-677):
 //   k_node      update_tau2! (scalar draw from carried sums) + update_u_xi! (one wave per node, log-space weights)
 //   k_xpass     W = lowtri(u' L u), sz = sqrt(S) z1, partial GEMVs X W and X sz          (reads X once)
-//   k_gram      X diag(S) X' by v_mfma_f64_16x16x4_f64, split-K partial tiles             (reads X once)
-//   k_gram_reduce, k_chol_step x n_pad/32   E = [G + I ; I] -> [L ; L^-T]  (right-looking blocked Cholesky, one launch per panel)
+//   k_gram / k_gram8   X diag(S) X' by v_mfma_f64_16x16x4_f64, split-K partial tiles; lower triangle only, and of a diagonal tile only
+//               what lies on or below the diagonal at block / MFMA-tile granularity (BNR_GRAM_SKIP_DEAD)    (reads X once)
+//   k_chol_step x n_pad/32   E = [G + I ; I] -> [L ; L^-T]  (right-looking blocked Cholesky, one launch per panel; launch 0 also sums the
+//               split-K partials; k_gram_reduce / k_chol_step2 for the two-panel variant of large n)
 //   k_rhs, k_solve_w, k_solve_a4   a4 = (G+I)^-1 (a1 - a3) = Y (Y' b); X gamma_new from n-vectors (no third pass over X)
 //   k_backproj  gamma (back-projection X' a4), update_D! (GIG draws), partial sums for theta and Lambda (reads X once)
 //   k_tail      update_theta!, update_Delta!, update_M!, update_mu!, update_Lambda!, update_pi!, carried sums
@@ -20,6 +22,8 @@
 // of descriptors indexed by the grid's chain coordinate: bnr_many); the arithmetic of a chain is the same in both.
 // Outside the sweep: k_init_prior (initialize_variables!), k_fetch_cols / k_load_cols (Table layout), k_rhat_stats
 // (split-Rhat message), k_summary (Summary statistics).
+// Experiments (rounds 3-4: persistent / resident Gram kernels, left-looking and data-flow factorizations, gates, ...) live in
+// bnr_experiments.h, included at the end of this file only with -DBNR_EXPERIMENTS; the shipped library has none of them.
 #pragma once
 #include "bnr_rng.h"
 
