@@ -159,9 +159,13 @@ def Summary(results, interval=95, digits=3):
 
 # ------------------------------------------------------------------------------------------ chain placement
 def _dist():
+    """torch.distributed if THE CALLER has imported and initialised it, else None.  Never imports torch itself: a process group can only
+    exist if the caller imported torch already, and importing it here would map the torch wheel's own libamdhip64 in front of
+    libbnr_hip.so's (/opt/rocm) in a process that has not created a chain yet -- the load-order guard of _capi.lib() then refuses to run."""
+    import sys
+    dist = sys.modules.get("torch.distributed")
     try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
+        if dist is not None and dist.is_available() and dist.is_initialized():
             return dist
     except Exception:
         pass

@@ -324,3 +324,21 @@ except _capi.BnrError as e:
         assert out[1] == "REFUSED", out
     out = subprocess.run([sys.executable, str(script), "lib"], capture_output=True, text=True, timeout=300).stdout.split()
     assert out[0] == "OWN" and out[1] in ("CREATED", "OTHER:"), out      # OTHER: no GPU in this container (BNR_ERR_HIP from hipGetDeviceCount)
+
+
+def test_fit_in_a_fresh_process_does_not_pull_in_torch():
+    """The README's first example -- `import bnr_amd; bnr_amd.Fit(...)` in a fresh process -- must reach the library with nothing else
+    loaded: the chain-placement helpers look for a process group the CALLER initialised and never import torch themselves (importing
+    it would map the torch wheel's own HIP runtime in front of the library's and trip the load-order guard above)."""
+    code = ("import sys; sys.path.insert(0, %r); import bnr_amd\n"
+            "X, y, _ = bnr_amd.make_synthetic(20, 5, 2, seed=1)\n"
+            "try:\n"
+            "    bnr_amd.generate_samples(X, y, 2, nburn=4, nsamp=4, num_chains=2, seed=3, x_transform=False, suppress_timer=True)\n"
+            "    print('RAN')\n"
+            "except Exception as e:\n"
+            "    print('RAISED', str(e))\n"
+            "print('TORCH' if 'torch' in sys.modules else 'NOTORCH')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300).stdout
+    assert "NOTORCH" in out, out
+    assert "another HIP runtime" not in out, out            # (without a GPU the call ends in BNR_ERR_HIP from hipGetDeviceCount: no CPU fallback)
+    assert out.startswith("RAN") or "no ROCm-capable device" in out or "HIP" in out, out

@@ -137,3 +137,18 @@ def test_chains_sharded_over_two_ranks(gpu, tmp_path):
     assert bool(r0["has_state"]) and not bool(r1["has_state"])          # only chain 1's trace is returned (gibbs.jl:788)
     allg = np.stack([r0["g1"][:, :, 0], r1["g2"][:, :, 0], r0["g3"][:, :, 0]], axis=2)
     assert np.allclose(r0["rg"], bo.rhat(allg), rtol=1e-10)
+
+
+def test_fit_in_a_fresh_process(gpu, tmp_path):
+    """The README's first example in a process of its own: nothing loaded before `bnr_amd.Fit`, two chains as one lockstep group on the GPU,
+    Summary on the device.  (Round 4: the chain-placement helpers imported torch, whose wheel maps its own HIP runtime -- the library's
+    load-order guard then refused to create chains in any process that had not created one before.)"""
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, bnr_amd\n"
+            "X, y, _ = bnr_amd.make_synthetic(60, 8, 3, seed=5)\n"
+            "res = bnr_amd.Fit(X, y, 3, V=8, nburn=40, nsamples=40, num_chains=2, seed=11, x_transform=False, suppress_timer=True, psrf_cutoff=50.0)\n"
+            "g = [v for k, v in res.state.items() if np.asarray(v).shape[1:] == (36, 1)]\n"
+            "print('OK', len(g) >= 2 and all(np.isfinite(np.asarray(v)).all() for v in g), 'torch' in sys.modules)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-4000:]
+    assert out.stdout.strip().endswith("OK True False"), out.stdout[-2000:] + out.stderr[-2000:]
+
