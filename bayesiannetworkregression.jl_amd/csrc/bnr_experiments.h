@@ -1211,3 +1211,55 @@ __global__ __launch_bounds__(256) void k_chol_df(const SRC chain_src, int s, int
     if (bad && tid == 0 && w == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[7], 1ull); }
     if (late && lane == 0) atomicAdd((unsigned long long *)&cd.counters[8], 1ull);       // a hand-over never came: the run fails loudly ("stream ordering violated")
 }
+
+// ----------------------------------------------------------------------------------------- small problems: one launch, one workgroup per chain
+// k_chol_small<NBK> (n_pad = 32 NBK, NBK = 2 or 4, i.e. n <= 128): the SAME factorization as k_chol_step x NBK -- every element sees the K-slice
+// partials summed in k_gram_reduce's order, then the panels' rank-32 updates in ascending order (eight MFMA k-steps each), then the same column
+// sweep: bitwise the same E -- by ONE workgroup of NBK teams of 256 threads.  At these sizes a panel step is 3.3 us of sweep + 0.9 us of update, and
+// the launch-per-panel version pays 2.3 us of launch gap and a cold round trip on top, NBK times, on what is half of the sweep's critical chain
+// (tools/r4_exp3.py with BNR_SHAPE=70,19,5: 87.0 us per sweep, 72.4 with the panel steps 1.. skipped).
+// MEASURED SLOWER (tools/r4_small.py, notes r4 H): bitwise equal, but n = 70: 108 us per sweep against 84, n = 128: 134 against 95 -- replayed from the
+// captured graph, the scalar branch's kernels are not dispatched on the XCD where this 25 us kernel runs until it ends (the same effect that keeps
+// k_node away from k_chol_df), so the two branches of the sweep run one after the other.  n_pad = 64: a draw (71.4 / 70.9).
+//   Team t is the panel workgroup of slot t + 1 (k_chol_step's blockIdx.y): at step p it owns block row rho of block column p, touches it for the first
+//   time there (K-slice partials of G + I, or the identity block of Y), applies the panels 0 .. p-1 to it and to its own copy of the diagonal block
+//   (left-looking: with at most three panels behind there is no trailing update worth a workgroup of its own), and sweeps [D ; own] (bnr_panel_sweep,
+//   whose barriers are workgroup-wide: all teams run it in lockstep).  The swept blocks go to E; the next step's fragment loads follow a barrier
+//   of the same workgroup (one CU, one L1: no cache maintenance).  No reduction pass, no stamps: the kernel follows the Gram on its stream.
+//   grid = chains; block = 256 NBK threads; dynamic LDS = NBK panel areas.
+template <class SRC, int NBK>
+__global__ __launch_bounds__(256 * NBK) void k_chol_small(const SRC chain_src, int s)
+{
+    BNR_CRITICAL_PATH();
+    (void)s;
+    const bnr_dev &cd = chain_src.get_x();
+    extern __shared__ double sh_small_[];
+    const int team = threadIdx.x >> 8, tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;
+    bnr_panel_lds &sh = ((bnr_panel_lds *)sh_small_)[team];
+    const size_t ld = bnr_ldE(cd.n_pad);
+    const int mt = wave >> 1, nt = wave & 1, ln = lane & 15, lq = lane >> 4;
+    double *E = cd.E;
+    for (int p = 0; p < NBK; ++p) {
+        const int b = team + 1, pc = p * BNR_NB;
+        const int rho = b < NBK - p ? p + b : NBK + (b - (NBK - p));     // matrix rows p+1 .. NBK-1, then identity rows 0 .. p
+        bnr_d4 cD, cB, t1[1][1];
+        bnr_gsum_frag<1, 2>(cd, p, p, mt, nt, ln, lq, t1, false);
+        cD = t1[0][0];
+        int q0 = 0;                                                       // the first panel that has a block in my block row
+        if (rho < NBK) { bnr_gsum_frag<1, 2>(cd, rho, p, mt, nt, ln, lq, t1, false); cB = t1[0][0]; }
+        else {
+            q0 = rho - NBK;                                               // identity row r: I in block column r, nothing before it
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cB[r] = (q0 == p && nt * 16 + ln == mt * 16 + lq + 4 * r) ? 1.0 : 0.0;
+        }
+        for (int q = 0; q < p; ++q) {
+            const size_t kc = (size_t)q * BNR_NB;
+            const double *colrows = E + (size_t)(pc + mt * 16) + ld * kc;
+            cD = bnr_tile_update(colrows, E + (size_t)(pc + nt * 16) + ld * kc, ld, lane, cD);
+            if (q >= q0) cB = bnr_tile_update(colrows, E + (size_t)(rho * BNR_NB + nt * 16) + ld * kc, ld, lane, cB);
+        }
+        const int bad = bnr_panel_sweep(sh, cD, cB, tid, E + (size_t)(rho * BNR_NB) + ld * (size_t)pc, ld);
+        if (bad && threadIdx.x == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[7], 1ull); }
+        __syncthreads();                                                  // the swept blocks of panel p are in memory before anybody's next fragment loads
+    }
+}

@@ -57,6 +57,7 @@ struct bnr_exec {
     std::vector<hipEvent_t> fj;                         // fork/join events
     size_t fj_next = 0;
     int overlap = 1;
+    int nop_fork = 0;                                   // (experiments) 1: an empty kernel is captured as the first forked branch of every sweep (needs stream4)
     int resv_mask = 0x80;                               // k_gram8q: cu ids (inside a shader engine) it keeps off -- 0x80 = cu id 7 of every SE = 32 CUs
     int crit_origin = 0;                                // 1: the critical chain (Gram, factorization, solve, back-projection) stays on the capture origin's queue and the scalar branch is the forked one; 2: the same with an empty kernel captured as the first fork
     int gram_variant = 0;                               // 0: chosen per launch; 8 / 16: k_gram8 / k_gram forced (tests, experiments)
@@ -155,6 +156,7 @@ static int ensure_lds_attributes(int device)
                          (const void *)&k_backproj<bnr_many>, (const void *)&k_solve_a4<bnr_one>, (const void *)&k_solve_a4<bnr_many>,
 #ifdef BNR_EXPERIMENTS
                          (const void *)&k_chol_ll<bnr_one>, (const void *)&k_chol_ll<bnr_many>, (const void *)&k_chol_df<bnr_one>, (const void *)&k_chol_df<bnr_many>,
+                         (const void *)&k_chol_small<bnr_one, 4>, (const void *)&k_chol_small<bnr_many, 4>,
                          (const void *)&k_gram_gate<bnr_one>, (const void *)&k_gram_gate<bnr_many>, (const void *)&k_backproj_group,
 #endif
                          (const void *)&k_xpass_group};
@@ -695,9 +697,21 @@ static bool dataflow(const bnr_exec &x)
     (void)x; return false;
 #endif
 }
+// small problems (n_pad <= 128): the whole factorization in ONE launch of one workgroup per chain (k_chol_small): factor_variant 5
+// (experiments build only: bitwise equal, measured slower -- profiles/round4_experiments_notes.txt H)
+static bool small_factor(const bnr_exec &x)
+{
+#ifdef BNR_EXPERIMENTS
+    if (x.shape->n_pad > 128 || left_looking(x)) return false;
+    return x.factor_variant == 5;
+#else
+    (void)x; return false;
+#endif
+}
 // the one-panel right-looking factorization (k_chol_step) is the one that runs, and its first launch takes over k_gram_reduce's work
 static bool reduce_in_chol(const bnr_exec &x)
 {
+    if (small_factor(x)) return true;                    // (k_chol_small sums the partial tiles at the first touch of every block: no reduction pass)
     if (dataflow(x)) return true;                        // (k_chol_df sums the partial tiles at the first touch of every block: no reduction pass at all)
     const bool one_panel = x.factor_variant == 0 || (x.factor_variant < 0 && !two_panel_default(x));
     return one_panel && x.fuse_reduce != 0;
@@ -868,6 +882,17 @@ static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
 {
     const int nbk = x.shape->n_pad / BNR_NB;
 #ifdef BNR_EXPERIMENTS
+    if (small_factor(x)) {
+        const size_t lds = (size_t)nbk * sizeof(bnr_panel_lds);
+        if (x.nb == 1) {
+            if (nbk == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_small<bnr_one, 2>), dim3(1), dim3(512), lds, st, bnr_one{*x.shape}, s);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_small<bnr_one, 4>), dim3(1), dim3(1024), lds, st, bnr_one{*x.shape}, s);
+        } else {
+            if (nbk == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_small<bnr_many, 2>), dim3(x.nb), dim3(512), lds, st, bnr_many{x.cds}, s);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_small<bnr_many, 4>), dim3(x.nb), dim3(1024), lds, st, bnr_many{x.cds}, s);
+        }
+        return;
+    }
     if (dataflow(x)) { BNR_LAUNCH(k_chol_df, dim3(8 * BNR_DF_WG), dim3(256), BNR_DF_LDS, st, x, s, x.nb); return; }
 #endif
     if (x.factor_variant == 2 || x.factor_variant == 3 || (x.factor_variant < 0 && two_panel_default(x))) {
@@ -1030,6 +1055,14 @@ static void launch_sweep(bnr_exec &x, int s, bool prev_tail)
     if (overlap) {
         hipEvent_t ef = next_event(x);
         HIPNOTE(hipEventRecord(ef, x.stream));
+#ifdef BNR_EXPERIMENTS
+        if (x.nop_fork && x.stream4) {
+            // an empty kernel as the FIRST-captured forked branch: a captured graph treats its first fork specially (notes r3 A.3, r4 F)
+            HIPNOTE(hipStreamWaitEvent(x.stream4, ef, 0));
+            hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, x.stream4);
+            HIPNOTE(hipEventRecord(ej[1] = next_event(x), x.stream4));
+        }
+#endif
         HIPNOTE(hipStreamWaitEvent(x.stream2, ef, 0));
         launch_gram(x, s, sb, timed);
         launch_chol(x, s, sb);
@@ -1522,7 +1555,7 @@ static int ensure_pipeline_streams(bnr_exec &x, int mode)
 // nothing a user can set starts a kernel that polls device memory
 static bool experimental_option(const char *name)
 {
-    for (const char *e : {"resv_mask", "crit_origin", "group_backproj", "linear", "linear_merge", "linear_debug", "pipeline", "gate_us"})
+    for (const char *e : {"nop_fork", "resv_mask", "crit_origin", "group_backproj", "linear", "linear_merge", "linear_debug", "pipeline", "gate_us"})
         if (!strcmp(name, e)) return true;
     return false;
 }
@@ -1562,16 +1595,21 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
     }
     if (!strcmp(name, "factor_variant")) {
 #ifdef BNR_EXPERIMENTS
-        const bool ok = value >= -1 && value <= 4;
+        const bool ok = value >= -1 && value <= 5;
 #else
         const bool ok = value >= -1 && value <= 3 && value != 1;
 #endif
-        if (!ok) return fail(BNR_ERR_BAD_ARG, "factor_variant must be -1 (auto), 0 (right-looking), 2 (right-looking, two panels per launch) or 3 (2 with the K = 128 trailing update); 1 (left-looking) and 4 (data-flow, one launch) are experiments (-DBNR_EXPERIMENTS)");
+        if (!ok) return fail(BNR_ERR_BAD_ARG, "factor_variant must be -1 (auto), 0 (right-looking), 2 (right-looking, two panels per launch) or 3 (2 with the K = 128 trailing update); 1 (left-looking), 4 (data-flow, one launch) and 5 (one workgroup per chain, n_pad <= 128) are experiments (-DBNR_EXPERIMENTS)");
         x.factor_variant = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "graph_k")) { if (value < 1 || value > 256) return fail(BNR_ERR_BAD_ARG, "graph_k out of range"); x.graph_k = (int)value; drop_graph(x); return BNR_OK; }
     if (!strcmp(name, "profiling")) { if (x.profiling != (int)value) drop_graph(x); x.profiling = (int)value; return BNR_OK; }
 #ifdef BNR_EXPERIMENTS
+    if (!strcmp(name, "nop_fork")) {
+        if (value < 0 || value > 1) return fail(BNR_ERR_BAD_ARG, "nop_fork must be 0 or 1");
+        if (value == 1 && !x.stream4) { HIPCHK(hipSetDevice(x.device)); HIPCHK(hipStreamCreateWithFlags(&x.stream4, hipStreamNonBlocking)); }
+        x.nop_fork = (int)value; drop_graph(x); return BNR_OK;
+    }
     if (!strcmp(name, "resv_mask")) {
         if (value < 0 || (value & ~0xfe) || __builtin_popcountll((unsigned long long)value) > 4) return fail(BNR_ERR_BAD_ARG, "resv_mask: bits 1..7 = cu ids inside a shader engine that the resident Gram leaves free, four at most");
         x.resv_mask = (int)value; drop_graph(x); return BNR_OK;

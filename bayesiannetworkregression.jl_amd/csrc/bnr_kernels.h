@@ -1169,7 +1169,7 @@ __device__ __forceinline__ double bnr_ld_fresh(const double *p, bool fresh)
 {
     return fresh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
-template <int NT>
+template <int NT, int KUSEL = 0>
 __device__ __forceinline__ void bnr_gsum_frag(const bnr_dev &cd, int rho, int c, int at0, int bt0, int ln, int lq, bnr_d4 (&out)[NT][NT], bool fresh)
 {
     const int ti = rho >> 1, tj = c >> 1, ntl = cd.ntile * (cd.ntile + 1) / 2;
@@ -1181,7 +1181,7 @@ __device__ __forceinline__ void bnr_gsum_frag(const bnr_dev &cd, int rho, int c,
         for (int bt = 0; bt < NT; ++bt) out[at][bt] = bnr_d4{0.0, 0.0, 0.0, 0.0};
     // KU slices per round, all in flight; a slice past the last one is read again from the last plane and enters as + 0.0, which
     // changes nothing (the running sum is never -0.0)
-    constexpr int KU = NT == 1 ? 8 : 4;
+    constexpr int KU = KUSEL ? KUSEL : (NT == 1 ? 8 : 4);   // (KUSEL: fewer slices in flight where registers are short: the same sums, slice by slice)
     const int klast = cd.ksplit - 1;
     for (int ks0 = 0; ks0 < cd.ksplit; ks0 += KU) {
         bnr_d4 v[KU][NT][NT];

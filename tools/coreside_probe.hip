@@ -67,7 +67,25 @@ static int run(int hog_lds, int small_lds, int prio, int hog_wg)
     CHK(hipFuncSetAttribute((const void *)&small_k<VS>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CHK(hipDeviceSynchronize());
     const int N = 100;
-    if (prio & 8) {                                  // the same pair as two branches of a captured graph
+    if (prio & 16) {                                 // two branches of CHAINS: branch 1 = nop -> hog -> nop, branch 2 = small -> small -> small (the last one's stamps are read)
+        hipGraph_t graph; hipGraphExec_t gexec; hipEvent_t ef, ej;
+        unsigned long long *out2; CHK(hipMalloc(&out2, 2 * 128 * 8));
+        CHK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); CHK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+        CHK(hipStreamBeginCapture(s1, hipStreamCaptureModeThreadLocal));
+        hipLaunchKernelGGL(small_k<64>, dim3(1), dim3(64), 1024, s1, out2);                       // a common predecessor (the "back-projection")
+        CHK(hipEventRecord(ef, s1)); CHK(hipStreamWaitEvent(s2, ef, 0));
+        hipLaunchKernelGGL(small_k<64>, dim3(8), dim3(64), 1024, s1, out2);                       // branch 1: a short kernel in front of the hog (the "Gram")
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hog<VG, AG>), dim3(hog_wg), dim3(256), hog_lds, s1, t, 300, prio);
+        hipLaunchKernelGGL(small_k<64>, dim3(8), dim3(64), 1024, s1, out2);                       // ... and one behind it (the "solve")
+        hipLaunchKernelGGL(small_k<VS>, dim3(N), dim3(64), small_lds, s2, out2);                  // branch 2: "k_tail" (10 us)
+        hipLaunchKernelGGL(small_k<VS>, dim3(N), dim3(64), small_lds, s2, out2);                  //           another 10 us
+        hipLaunchKernelGGL(small_k<VS>, dim3(N), dim3(64), small_lds, s2, out);                   //           "k_node": when do its workgroups start?
+        CHK(hipEventRecord(ej, s2)); CHK(hipStreamWaitEvent(s1, ej, 0));
+        CHK(hipStreamEndCapture(s1, &graph));
+        CHK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+        for (int rep = 0; rep < 2; ++rep) { CHK(hipGraphLaunch(gexec, s1)); CHK(hipDeviceSynchronize()); }
+        CHK(hipGraphExecDestroy(gexec)); CHK(hipGraphDestroy(graph)); (void)hipFree(out2);
+    } else if (prio & 8) {                                  // the same pair as two branches of a captured graph
         hipGraph_t graph; hipGraphExec_t gexec; hipEvent_t ef, ej;
         CHK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); CHK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
         CHK(hipStreamBeginCapture(s1, hipStreamCaptureModeThreadLocal));
@@ -88,12 +106,14 @@ static int run(int hog_lds, int small_lds, int prio, int hog_wg)
     unsigned long long ht[2], ho[2 * 128];
     CHK(hipMemcpy(ht, t, 16, hipMemcpyDeviceToHost)); CHK(hipMemcpy(ho, out, 2 * N * 8, hipMemcpyDeviceToHost));
     int during = 0, after = 0;
-    double latest = 0;
+    double latest = 0, latest0 = -1e9, latestx = -1e9;
     for (int i = 0; i < N; ++i) {
         const double rel = ((double)ho[2 * i] - (double)ht[0]) / 100.0;
         if (ho[2 * i] < ht[1]) ++during; else ++after;
         latest = std::max(latest, rel);
+        if (ho[2 * i + 1] == 0) latest0 = std::max(latest0, rel); else latestx = std::max(latestx, rel);
     }
+    if (prio & 16) printf("   chains of kernels: last small kernel's workgroups on XCD 0 start at %+.1f us at the latest, on the other XCDs at %+.1f us (hog: 0 .. 300 us)\n", latest0, latestx);
     printf("hog %3d wg x %3d VGPR + %2d AGPR x %6d B LDS prio %d | small %3d VGPR x %6d B LDS : %3d of %d small workgroups started while the hog ran (300 us), %3d after; latest start at %+.1f us\n",
            hog_wg, VG, AG, hog_lds, prio, VS, small_lds, during, N, after, latest);
     (void)hipFree(t); (void)hipFree(out); (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2);
@@ -130,5 +150,10 @@ int main()
     run<64, 64>(32 * 1024, 8 * 1024, 8, 256);
     run<128, 128>(95 * 1024, 41 * 1024, 8, 256);
     run<180, 128, 72>(95 * 1024, 41 * 1024, 8, 256);
+    printf("prio bit 4: two branches of kernel CHAINS in a captured graph (bit 1: the hog's workgroups stay on XCD 0 only)\n");
+    run<180, 240, 72>(95 * 1024, 41 * 1024, 16, 256);
+    run<180, 240, 72>(95 * 1024, 41 * 1024, 16 + 2, 256);
+    run<64, 64>(8 * 1024, 8 * 1024, 16 + 2, 256);
+    run<64, 64>(8 * 1024, 8 * 1024, 16 + 2, 8);
     return 0;
 }

@@ -6,11 +6,13 @@ os.environ.setdefault("BNR_HIP_LIB", os.path.join(os.path.dirname(os.path.dirnam
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bnr_amd
 K, W = 800, 200
-X, y, _ = bnr_amd.make_synthetic(500, 100, 7, seed=20240501)
+n_, V_, R_ = (int(v) for v in os.environ.get("BNR_SHAPE", "500,100,7").split(","))      # BNR_SHAPE=n,V,R selects another size
+X, y, _ = bnr_amd.make_synthetic(n_, V_, R_, seed=20240501)
+print("shape n=%d V=%d R=%d" % (n_, V_, R_))
 L = bnr_amd.lib()
 for nb in (8, 1):
     tot = W + K * 12 + 1
-    ch = bnr_amd.Chain(X, y, 7, tot, 5, 1)
+    ch = bnr_amd.Chain(X, y, R_, tot, 5, 1)
     members = [ch] + [bnr_amd.Chain.like(ch, 5, c, tot) for c in range(2, nb + 1)]
     for c in members: c.init_prior()
     g = bnr_amd.Group(members) if nb > 1 else ch
