@@ -237,8 +237,8 @@ int bnr_debug_set_exp(int32_t device, int32_t flags);
  *   "profiling" 1: record HIP events around every k_gram launch (forces eager launches), see bnr_chain_last_timing
  *   "factor_variant" -1 (default): chosen by size -- 0 below n_pad = 1024, 3 from there on; 0: right-looking factorization, one
  *               32-column panel per launch (k_gram_reduce + k_chol_step); 2: right-looking, two panels per launch (k_chol_step2); 3: 2 with
- *               the whole trailing matrix updated at every other launch only (K = 128); (1: left-looking k_chol_ll, 4: data-flow k_chol_df --
- *               -DBNR_EXPERIMENTS only)
+ *               the whole trailing matrix updated at every other launch only (K = 128); (1: left-looking k_chol_ll, 4: data-flow k_chol_df, 5: one workgroup per
+ *               chain k_chol_small -- -DBNR_EXPERIMENTS only)
  *   "fuse_reduce" 1 / -1 (default): launch 0 of the one-panel factorization also sums the Gram's K-split partial tiles (no k_gram_reduce
  *               launch); 0: separate reduction pass
  *   "group_xpass" -1 (default): a lockstep group whose members share the device copy of X (bnr_chain_create_like) runs ONE X pass
@@ -246,7 +246,7 @@ int bnr_debug_set_exp(int32_t device, int32_t flags);
  *   "split_sums" -1 (default): a chain run alone computes the back-projection's partial sums (update_theta!, update_Lambda!) in a launch of
  *               their own in front of the scalar tail, off the critical chain; 1: always; 0: inside the back-projection
  *   "spw_cap"   1..4 (default 4): super blocks per update workgroup of the factorization, at most (diagnostics)
- *   Experiments ("pipeline", "gate_us", "linear", "linear_merge", "linear_debug", "group_backproj", "resv_mask", "crit_origin"; rounds 3-4,
+ *   Experiments ("nop_fork", "pipeline", "gate_us", "linear", "linear_merge", "linear_debug", "group_backproj", "resv_mask", "crit_origin"; rounds 3-4,
  *               profiles/round*_experiments_notes.txt): all measured no faster, part of them poll device memory.  They exist only in a library
  *               built with -DBNR_EXPERIMENTS (csrc/bnr_experiments.h, tools/r4_build_variants.sh); the shipped library refuses them by name.
  *   "byte_x"    (chains only) 0: the X passes read the f64 matrix although a byte image of X exists; 1 (default): the byte image

@@ -1205,7 +1205,7 @@ def test_experimental_options_are_refused_by_the_shipped_library(gpu, test1):
     g = bnr_amd.Group([ch, mate])
     for target in (ch, g):
         for name, value in (("pipeline", 1), ("linear", 2), ("linear_merge", 1), ("gate_us", 100), ("group_backproj", 1), ("resv_mask", 0x80),
-                            ("crit_origin", 1), ("gram_variant", 9), ("gram_variant", 10), ("gram_variant", 13), ("factor_variant", 1), ("factor_variant", 4)):
+                            ("crit_origin", 1), ("gram_variant", 9), ("gram_variant", 10), ("gram_variant", 13), ("factor_variant", 1), ("factor_variant", 4), ("factor_variant", 5), ("nop_fork", 1)):
             with pytest.raises(bnr_amd.BnrError, match="BNR_EXPERIMENTS"):
                 target.set_option(name, value)
     assert bnr_amd.lib().bnr_debug_set_exp(0, 1) != 0
