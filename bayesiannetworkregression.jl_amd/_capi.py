@@ -73,6 +73,7 @@ _SIGS = {
     "bnr_comm_create_callback": (C.c_int, [C.c_int32, C.c_int32, ALLGATHER_CB, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bnr_comm_destroy": (C.c_int, [C.c_void_p]),
     "bnr_comm_allgather": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64]),
+    "bnr_comm_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 5),
     "bnr_rhat": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, _dp, _dp]),
     "bnr_rhat_from_stats": (C.c_int, [_dp, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "bnr_chain_ess_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp]),
@@ -466,6 +467,13 @@ class Comm:
         out = np.empty(self.world * s.size)
         check(self.L.bnr_comm_allgather(self.h, _ptr(s), _ptr(out), s.size))
         return out.reshape(self.world, s.size)
+
+    def info(self):
+        """bnr_comm_info: what the transport itself reports -- {'kind': 'rccl' | 'callback', 'rank', 'world', 'rccl_ranks' (ncclCommCount; 0 unless RCCL), 'rccl_rank'}."""
+        v = [C.c_int32() for _ in range(5)]
+        check(self.L.bnr_comm_info(self.h, *[C.byref(x) for x in v]))
+        kind, rank, world, nr, ur = [x.value for x in v]
+        return {"kind": {0: "none", 1: "rccl", 2: "callback"}[kind], "rank": rank, "world": world, "rccl_ranks": nr, "rccl_rank": ur}
 
     def close(self):
         h, self.h = getattr(self, "h", None), None

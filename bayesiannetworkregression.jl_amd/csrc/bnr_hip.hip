@@ -2080,6 +2080,8 @@ struct rccl_api {
     int (*CommInitRank)(void **, int, bnr_unique_id, int) = nullptr;     // ncclUniqueId is a 128-byte struct passed by value
     int (*CommDestroy)(void *) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
+    int (*CommUserRank)(void *, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
 rccl_api g_rccl;
@@ -2116,6 +2118,8 @@ static int rccl_load()
     a.CommInitRank = (int (*)(void **, int, bnr_unique_id, int))dlsym(h, "ncclCommInitRank");
     a.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
     a.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+    a.CommCount = (int (*)(void *, int *))dlsym(h, "ncclCommCount");
+    a.CommUserRank = (int (*)(void *, int *))dlsym(h, "ncclCommUserRank");
     a.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather) return fail(BNR_ERR_HIP, "librccl.so lacks an expected symbol");
     g_rccl = a;
@@ -2164,6 +2168,28 @@ int bnr_comm_destroy(bnr_comm *c)
     if (c->drecv) (void)hipFree(c->drecv);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return BNR_OK;
+}
+// what a communicator is, as the transport itself reports it: kind 1 = RCCL (rccl_ranks / rccl_rank = ncclCommCount / ncclCommUserRank of
+// the library's communicator, i.e. how many ranks RCCL really connected -- not the number the caller asked for), kind 2 = host callback
+// (rccl_ranks = 0).  NULL communicator: one rank, no transport (kind 0).
+int bnr_comm_info(bnr_comm *c, int32_t *kind, int32_t *rank, int32_t *world, int32_t *rccl_ranks, int32_t *rccl_rank)
+{
+    int k = 0, r = 0, w = 1, nr = 0, ur = -1;
+    if (c) {
+        r = c->rank; w = c->world;
+        if (c->fn) k = 2;
+        else if (c->nccl) {
+            k = 1;
+            if (g_rccl.CommCount) { int e = g_rccl.CommCount(c->nccl, &nr); if (e) return rccl_fail("ncclCommCount", e); }
+            if (g_rccl.CommUserRank) { int e = g_rccl.CommUserRank(c->nccl, &ur); if (e) return rccl_fail("ncclCommUserRank", e); }
+        }
+    }
+    if (kind) *kind = k;
+    if (rank) *rank = r;
+    if (world) *world = w;
+    if (rccl_ranks) *rccl_ranks = nr;
+    if (rccl_rank) *rccl_rank = ur;
     return BNR_OK;
 }
 // all-gather of `count` doubles per rank: send (host) -> recv (host, world * count, rank order)

@@ -123,15 +123,41 @@ def spawn_ranks(a):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL across processes)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
-    out0 = procs[0].communicate()[0]
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=600 if rc == 0 else 20)
-        except subprocess.TimeoutExpired:
-            p.kill()                                          # (our own child, by its pid)
-            p.wait()
-        rc = rc or p.returncode
+    # every child is watched, not only rank 0: a rank that dies at start-up (bad device index, the library refusing to load) would leave the
+    # others waiting in the rendezvous until torch's own timeout (~30 min) with the real error buried.  The first non-zero exit ends the run:
+    # the remaining children (ours, addressed by pid) are terminated, that child's code is returned; the whole wait has an overall deadline.
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)     # rank 0's one line (drained so that its pipe never fills)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("BNR_BENCH_DEADLINE_S", "3000"))
+    rc, failed = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed, rc = bad[0]
+            rc = rc if rc > 0 else 128 - rc             # a child killed by signal s reports -s
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            failed, rc = -1, 124
+            break
+        time.sleep(0.2)
+    if failed is not None:
+        sys.stderr.write("bench.py: %s; stopping the other ranks\n" % ("rank %d exited with code %d" % (failed, rc) if failed >= 0 else "the ranks did not finish before the deadline"))
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()                                      # (our own child, by its pid)
+                p.wait()
+    reader.join(timeout=10)
+    out0 = "".join(c for c in chunks if c)
     sys.stdout.write(out0)
     sys.stdout.flush()
     return rc
@@ -163,7 +189,9 @@ def main():
         world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
         total_chains = world * a.chains_per_gpu if a.chains_per_gpu > 0 else a.chains
         ids = [c for c in range(1, total_chains + 1) if (c - 1) % world == rank]
-        line = {"rank": rank, "world": world, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "chain_ids": ids, "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}
+        if os.environ.get("BNR_BENCH_DRY_FAIL_RANK") == str(rank):      # test hook: this rank dies at start-up, before the rendezvous
+            raise SystemExit(7)
+        line = {"rank": rank, "world": world, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "chain_ids": ids, "chains_held": len(ids), "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}
         if world > 1:                                      # the ranks meet over gloo on the loopback, as the real run's rendezvous does
             import torch.distributed as dist
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
@@ -173,9 +201,9 @@ def main():
                 dist.all_gather_object(box, line)
                 dist.barrier()
                 dist.destroy_process_group()
-            line = {"dry_ranks": box, "n_gpus": world}
+            line = {"dry_ranks": box, "n_gpus": world, "rccl_ranks": 0, "chains_held": [b["chains_held"] for b in sorted(box, key=lambda b: b["rank"])]}
         else:
-            line = {"dry_ranks": [line], "n_gpus": 1}
+            line = {"dry_ranks": [line], "n_gpus": 1, "rccl_ranks": 0, "chains_held": [line["chains_held"]]}
         if rank == 0:
             print(json.dumps(line))
         return
@@ -264,6 +292,9 @@ def main():
         chains.append(ch)
     # several chains on one GPU advance in lockstep: one launch per kernel of a sweep covers all of them
     runner = bnr_amd.Group(chains) if C > 1 else chains[0]
+    # what the N-rank run really was, as the transport reports it: ranks RCCL connected (ncclCommCount) and the chains every rank holds
+    comm_info = comm.info() if comm is not None else {"kind": "none", "rank": 0, "world": 1, "rccl_ranks": 0, "rccl_rank": -1}
+    held = comm.allgather(np.array([float(rank), float(local_rank), float(C), float(comm_info["rccl_ranks"])])) if comm is not None else np.array([[0.0, float(local_rank), float(C), 0.0]])
     if not a.overlap:
         runner.set_option("overlap", 0)
     if a.graph_k > 0:
@@ -405,6 +436,8 @@ def main():
             "ess_gamma": None if ess is None else {"min": float(np.nanmin(ess[:q])), "median": float(np.nanmedian(ess[:q])),
                                                    "draws": int(nsamp * total_chains), "min_per_second": float(np.nanmin(ess[:q]) / dt)},
             "counters": counters, "rhat_exchange": exchange,
+            "rccl_ranks": int(comm_info["rccl_ranks"]), "comm_kind": comm_info["kind"], "chains_held": [int(r[2]) for r in held],
+            "ranks": [{"rank": int(r[0]), "local_rank": int(r[1]), "chains_held": int(r[2]), "rccl_ranks_seen": int(r[3])} for r in held],
         }
         if single is not None:
             out["single_chain"] = single

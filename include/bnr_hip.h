@@ -28,8 +28,8 @@
 extern "C" {
 #endif
 
-#define BNR_ABI_VERSION 5   /* 2: + bnr_chain_create_like, bnr_group_*, bnr_chain_summary; 3: + bnr_*_prepare; 4: + bnr_comm_*, bnr_rhat;
-                               5: + bnr_chain_create_typed, bnr_chain_create_from_matrices, bnr_device_synchronize (all additive) */
+#define BNR_ABI_VERSION 6   /* 2: + bnr_chain_create_like, bnr_group_*, bnr_chain_summary; 3: + bnr_*_prepare; 4: + bnr_comm_*, bnr_rhat;
+                               5: + bnr_chain_create_typed, bnr_chain_create_from_matrices, bnr_device_synchronize; 6: + bnr_comm_info (all additive) */
 
 enum {
     BNR_OK = 0,
@@ -199,6 +199,11 @@ int bnr_comm_create_rccl(const bnr_unique_id *id, int32_t rank, int32_t world, i
 int bnr_comm_create_callback(int32_t rank, int32_t world, bnr_allgather_fn fn, void *ctx, bnr_comm **out);
 int bnr_comm_destroy(bnr_comm *comm);
 int bnr_comm_allgather(bnr_comm *comm, const double *send, double *recv, int64_t count);   /* host buffers; comm NULL = copy */
+/* What the transport itself reports (any out pointer may be NULL): kind 0 = no communicator (one rank), 1 = RCCL, 2 = host callback;
+ * rank / world as given at creation; rccl_ranks / rccl_rank = ncclCommCount / ncclCommUserRank of the library's communicator (0 / -1
+ * unless kind 1) -- the number of ranks RCCL really connected, which a multi-GPU run reports beside its throughput (the reference's
+ * counterpart is nworkers() after addprocs, gibbs.jl:946-948). */
+int bnr_comm_info(bnr_comm *comm, int32_t *kind, int32_t *rank, int32_t *world, int32_t *rccl_ranks, int32_t *rccl_rank);
 int bnr_rhat(bnr_chain *const *chains, int32_t nchains_local, int32_t nchains_total, bnr_comm *comm, int32_t burn, int32_t nsamp,
              double *rhat_xi, double *rhat_gamma);
 

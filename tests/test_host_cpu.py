@@ -244,10 +244,11 @@ dist.barrier(); dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("num_chains", [2, 3, 1])
-def test_rhat_exchange_two_ranks_gloo(tmp_path, num_chains):
+@pytest.mark.parametrize("num_chains,world", [(2, 2), (3, 2), (1, 2), (8, 3)])
+def test_rhat_exchange_two_ranks_gloo(tmp_path, num_chains, world):
     """World size 2 over gloo: chains sharded round-robin, per-chain messages all-gathered, every rank finishes the
-    same Rhat (the RCCL path of bench.py / generate_samples uses the same code with backend nccl)."""
+    same Rhat (the RCCL path of bench.py / generate_samples uses the same code with backend nccl).  (8, 3): the fit's 8 chains on
+    three ranks -- an uneven 3 / 3 / 2 split (gibbs.jl:946-957, 771-789)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -255,11 +256,14 @@ def test_rhat_exchange_two_ranks_gloo(tmp_path, num_chains):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT))
     out = str(tmp_path / "rhat")
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(port), str(num_chains), out]) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(port), str(num_chains), out]) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=180) == 0
-    r0, r1 = np.load(out + ".0.npy"), np.load(out + ".1.npy")
-    assert np.array_equal(r0, r1)
+    r0 = np.load(out + ".0.npy")
+    for r in range(1, world):
+        assert np.array_equal(r0, np.load(out + ".%d.npy" % r))
+    if (num_chains, world) == (8, 3):
+        assert [len([c for c in range(1, 9) if (c - 1) % 3 == r]) for r in range(3)] == [3, 3, 2]
     ref = np.stack([np.random.default_rng(100 + c).random(36) for c in range(1, num_chains + 1)])
     assert np.allclose(r0, bnr_amd.rhat_from_stats(ref, 20))
 
@@ -286,9 +290,29 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads(out.stdout.strip())
     assert [r["chain_ids"] for r in sorted(d["dry_ranks"], key=lambda r: r["rank"])] == [[1, 4], [2, 5], [3]]
+    assert d["chains_held"] == [2, 2, 1] and d["rccl_ranks"] == 0
     # a launcher that started a different number of ranks than --gpus says: refused, loudly
     out = subprocess.run([sys.executable, bench, "--gpus", "4", "--dry-ranks"], env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "must agree" in out.stderr
+
+
+def test_bench_eight_ranks_dry_and_a_rank_that_dies_at_start_up():
+    """The N = 8 layout of BASELINE configs[2] (one chain per GPU) through the same launcher, rendezvous and gather as the real run, without a
+    GPU: eight ranks, chain c on rank c - 1, the line carries what every rank holds.  And the launcher watches ALL its children: a rank that
+    dies before the rendezvous ends the run at once with that rank's exit code (not after torch's rendezvous timeout)."""
+    import time
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, bench, "--gpus", "8", "--dry-ranks"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout.strip())
+    assert d["n_gpus"] == 8 and d["chains_held"] == [1] * 8 and d["rccl_ranks"] == 0
+    assert [r["chain_ids"] for r in sorted(d["dry_ranks"], key=lambda r: r["rank"])] == [[c] for c in range(1, 9)]
+    assert sorted(r["local_rank"] for r in d["dry_ranks"]) == list(range(8))
+    t0 = time.time()
+    out = subprocess.run([sys.executable, bench, "--gpus", "3", "--dry-ranks"], env=dict(env, BNR_BENCH_DRY_FAIL_RANK="2"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 7 and "rank 2 exited with code 7" in out.stderr, (out.returncode, out.stderr[-2000:])
+    assert time.time() - t0 < 120
 
 
 def test_chains_are_refused_when_a_foreign_hip_runtime_was_loaded_first(tmp_path):
