@@ -336,6 +336,7 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     d.o_gamma = o; o += d.q;
     o = round_up(o, 16);
     d.o_S = o; o += d.q;
+    o += (d.q_pad - d.q) + 64;      // zeros behind S that nothing ever writes: the Gram reads S by column index up to two batches past q_pad without a clamp (X is zero there)
     d.rowlen = round_up(o, 16);
     d.eta = hyper->eta; d.zeta = hyper->zeta; d.iota = hyper->iota;
     d.aDelta = hyper->aDelta; d.bDelta = hyper->bDelta; d.nu = hyper->nu;

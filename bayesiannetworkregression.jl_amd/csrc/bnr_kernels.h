@@ -551,6 +551,22 @@ __global__ __launch_bounds__(256) void k_xpass_group(const bnr_many chain_src, i
 // blockIdx.y = K slice across workgroups (split-K partials, summed by k_gram_reduce).
 typedef double bnr_d4 __attribute__((ext_vector_type(4)));
 typedef double bnr_d2 __attribute__((ext_vector_type(2)));
+// Buffer loads: SGPR resource (base address) + 32-bit lane byte offset + SGPR byte offset.  The Gram loops advance the scalar offset only:
+// no address arithmetic on the vector ALU (global_load with a loop-variant scalar base is selected as a 64-bit vector add per load).
+typedef int bnr_i4 __attribute__((ext_vector_type(4)));
+typedef int bnr_i2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bnr_rsrc(const void *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7FFFFFFF, 0x00020000);     // raw buffer, no stride, 2 GiB window, gfx9 data format word
+}
+__device__ __forceinline__ bnr_d2 bnr_bufload_d2(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
+{
+    return __builtin_bit_cast(bnr_d2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ double bnr_bufload_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, 0));
+}
 // A Gram workgroup has stored its partial tile: count it for the tile's column (the factorization checks the count before its
 // first read of the column).  k_gram / k_gram8 are consumed after the kernel boundary: one relaxed atomic, no fence.
 // Only the opt-in left-looking / pipelined factorization reads the counts (builds with -DBNR_EXPERIMENTS): the default library does not
@@ -634,10 +650,12 @@ __device__ __forceinline__ void bnr_gram16_task(const bnr_gram_geom &cd, const d
     // staging: this thread moves rows (2 rp, 2 rp + 1) of columns c and c + 8 of both panels.  Addresses = wave-uniform base
     // of the batch (SGPRs, advanced by scalar adds) + a per-lane offset that never changes
     const int tg = threadIdx.x & 255, c = tg >> 5, rp = tg & 31;
-    const size_t offI = (size_t)(ti * BNR_GT + 2 * rp) + (size_t)c * ld, offJ = (size_t)(tj * BNR_GT + 2 * rp) + (size_t)c * ld;
-    const double *xb = cd.X + (size_t)eb * ld;                         // uniform: first column of this K-group
-    const double *sb = Sp + eb;                                        // uniform (columns >= q hold zeros in X: any finite S is fine)
-    const int smax = cd.q - 1 - eb;                                    // clamp for the S index
+    // (32-bit BYTE offsets: scalar base + zero-extended lane offset is the addressing form of global_load with an SGPR base; 16 columns of
+    // n_pad <= 16 384 rows stay below 4 GiB)
+    const unsigned offI = 8u * ((unsigned)(ti * BNR_GT + 2 * rp) + (unsigned)c * (unsigned)ld), offJ = 8u * ((unsigned)(tj * BNR_GT + 2 * rp) + (unsigned)c * (unsigned)ld);
+    const unsigned off8 = 8u * 8u * (unsigned)ld, offS = 8u * (unsigned)c;
+    const double *xb = bnr_sgpr_global(cd.X + (size_t)eb * ld);        // uniform: first column of this K-group, pinned to scalar registers (see bnr_gram8_task)
+    const double *sb = bnr_sgpr_global(Sp + eb);                       // uniform; S is followed by q_pad - q + 64 zeros in every trace row: no clamp
     const int PANEL = BNR_GRAM_KB * BNR_GT;                            // doubles per panel (16 columns x 64 rows)
     double *stg = sred + (size_t)kg * (4 * PANEL);                     // [buf][I|J][col][row ^ swizzle]
     const int woff = c * BNR_GT + ((2 * rp) ^ ((c & 1) << 4));         // columns c and c + 8 have the same parity
@@ -647,16 +665,17 @@ __device__ __forceinline__ void bnr_gram16_task(const bnr_gram_geom &cd, const d
     bnr_d4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};   // c[jt][it]
     bnr_d2 ri0, ri1, rj0, rj1;
     double sv0, sv1;
+    const __amdgpu_buffer_rsrc_t rX = bnr_rsrc(xb), rS = bnr_rsrc(sb);
+    const int bstep = BNR_GRAM_KB * (int)ld * 8;                       // bytes per batch (scalar)
 #define BNR_GRAM_LOAD(BIDX)                                                                               \
     do {                                                                                                  \
         const bool keep_ = (BNR_GRAM_EXP & 2) && (BIDX) > 1;                                              \
-        const double *cb_ = xb + (size_t)(keep_ ? 0 : (BIDX)) * (BNR_GRAM_KB * ld);                       \
-        int si_ = (BIDX) * BNR_GRAM_KB + c;                                                               \
-        if (!(BNR_GRAM_EXP & 1)) { sv0 = sb[si_ < smax ? si_ : smax]; sv1 = sb[si_ + 8 < smax ? si_ + 8 : smax]; } \
+        const int so_ = (keep_ ? 0 : (BIDX)) * bstep;                                                     \
+        if (!(BNR_GRAM_EXP & 1)) { sv0 = bnr_bufload_f64(rS, offS, (BIDX) * (BNR_GRAM_KB * 8)); sv1 = bnr_bufload_f64(rS, offS + 64u, (BIDX) * (BNR_GRAM_KB * 8)); } \
         else { sv0 = 1.0; sv1 = 1.0; }                                                                    \
         if (!keep_) {                                                                                     \
-            ri0 = *(const bnr_d2 *)(cb_ + offI); ri1 = *(const bnr_d2 *)(cb_ + offI + 8 * ld);            \
-            rj0 = *(const bnr_d2 *)(cb_ + offJ); rj1 = *(const bnr_d2 *)(cb_ + offJ + 8 * ld);            \
+            ri0 = bnr_bufload_d2(rX, offI, so_); ri1 = bnr_bufload_d2(rX, offI + off8, so_);              \
+            rj0 = bnr_bufload_d2(rX, offJ, so_); rj1 = bnr_bufload_d2(rX, offJ + off8, so_);              \
         }                                                                                                 \
     } while (0)
 #define BNR_GRAM_STORE(BUF)                                                                               \
@@ -689,35 +708,38 @@ __device__ __forceinline__ void bnr_gram16_task(const bnr_gram_geom &cd, const d
     if (BNR_GRAM_SKIP_DEAD && ti == tj && wi == 0 && wj == 1) {
         // the 32 x 32 block above the diagonal of a diagonal tile is read by nobody (k_gram_reduce copies it into the strictly upper
         // part of E, which the factorization never touches): its two waves only take part in the staging and leave zeros
-        for (int b = 0; b < nfull; ++b) {
-            BNR_GRAM_STORE((b + 1) & 1);
-            BNR_GRAM_LOAD(b + 2);
-            __syncthreads();
+        int b = 0;
+        for (; b + 1 < nfull; b += 2) {
+            BNR_GRAM_STORE(1); BNR_GRAM_LOAD(b + 2); __syncthreads();
+            BNR_GRAM_STORE(0); BNR_GRAM_LOAD(b + 3); __syncthreads();
         }
+        if (b < nfull) { BNR_GRAM_STORE(1); BNR_GRAM_LOAD(b + 2); __syncthreads(); }
         if (half) __syncthreads();
     } else if (BNR_GRAM_SKIP_DEAD && ti == tj && wi == wj) {
         // a diagonal 32 x 32 block: its upper 16 x 16 tile (c10: columns 16.., rows ..15) is read by nobody either -- three MFMAs per k-step
-        for (int b = 0; b < nfull; ++b) {
-            BNR_GRAM_COMPUTE(b & 1, 0, 2, true);
-            BNR_GRAM_STORE((b + 1) & 1);
-            BNR_GRAM_LOAD(b + 2);
-            BNR_GRAM_COMPUTE(b & 1, 2, 4, true);
-            __syncthreads();
-        }
-        if (half) { BNR_GRAM_COMPUTE(nfull & 1, 0, 2, true); __syncthreads(); }
+        // (two batches per trip, the buffer parity a literal: LDS addresses are "lane base + immediate", no address VALU in the loop)
+#define BNR_GRAM_BATCH_L(B, PAR, DIAG)                                                                    \
+        do {                                                                                              \
+            BNR_GRAM_COMPUTE(PAR, 0, 2, DIAG);                                                            \
+            BNR_GRAM_STORE((PAR) ^ 1);                                                                    \
+            BNR_GRAM_LOAD((B) + 2);                                                                       \
+            BNR_GRAM_COMPUTE(PAR, 2, 4, DIAG);                                                            \
+            __syncthreads();                                                                              \
+        } while (0)
+        int b = 0;
+        for (; b + 1 < nfull; b += 2) { BNR_GRAM_BATCH_L(b, 0, true); BNR_GRAM_BATCH_L(b + 1, 1, true); }
+        if (b < nfull) BNR_GRAM_BATCH_L(b, 0, true);
+        if (half) { if (nfull & 1) BNR_GRAM_COMPUTE(1, 0, 2, true); else BNR_GRAM_COMPUTE(0, 0, 2, true); __syncthreads(); }
     } else {
-    for (int b = 0; b < nfull; ++b) {
-        if (rot >= 0 && (b & 7) == 0) bnr_setprio3((rot + (b >> 3)) % BNR_G8P_WPC);
-        // first half of the batch, then the staging work of the next one, then the second half: the wait for the loads
-        // issued one batch ago and the LDS writes sit behind 8 MFMAs already in flight (measured: +4 % over staging first)
-        BNR_GRAM_COMPUTE(b & 1, 0, 2, false);
-        BNR_GRAM_STORE((b + 1) & 1);               // batch b+1; its buffer was released by the last barrier
-        BNR_GRAM_LOAD(b + 2);
-        BNR_GRAM_COMPUTE(b & 1, 2, 4, false);
-        __syncthreads();
+    // first half of the batch, then the staging work of the next one (batch b+1; its buffer was released by the last barrier), then the
+    // second half: the wait for the loads issued one batch ago and the LDS writes sit behind 8 MFMAs already in flight (measured: +4 %
+    // over staging first)
+    int b = 0;
+    for (; b + 1 < nfull; b += 2) { BNR_GRAM_BATCH_L(b, 0, false); BNR_GRAM_BATCH_L(b + 1, 1, false); }
+    if (b < nfull) BNR_GRAM_BATCH_L(b, 0, false);
+    if (half) { if (nfull & 1) BNR_GRAM_COMPUTE(1, 0, 2, false); else BNR_GRAM_COMPUTE(0, 0, 2, false); __syncthreads(); }
     }
-    if (half) { BNR_GRAM_COMPUTE(nfull & 1, 0, 2, false); __syncthreads(); }
-    }
+    (void)rot;
     (void)nbatch;
     // tile element (i,j) lives at [j*64 + i]; this lane: j = wj*32 + jt*16 + (lane>>4) + 4 r, i = wi*32 + it*16 + (lane&15)
     double *mine = sred + (size_t)kg * (BNR_GT * BNR_GT);
@@ -790,10 +812,14 @@ __device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const do
     // staging: this thread moves rows (2 rp, 2 rp + 1) of column c of both panels
     const int tg = tid & 255, c = tg >> 5, rp = tg & 31;
     // per-lane offsets inside a batch are small (8 columns): 32-bit, so that the loads use the scalar-base + 32-bit-offset form
-    const unsigned offI = (unsigned)(ti * BNR_GT + 2 * rp) + (unsigned)c * (unsigned)ld, offJ = (unsigned)(tj * BNR_GT + 2 * rp) + (unsigned)c * (unsigned)ld;
-    const double *xb = cd.X + (size_t)eb * ld;
-    const double *sb = Sp + eb;
-    const int smax = cd.q - 1 - eb;
+    // (in BYTES: scalar base + zero-extended 32-bit lane offset is the addressing form of global_load with an SGPR base)
+    const unsigned offI = 8u * ((unsigned)(ti * BNR_GT + 2 * rp) + (unsigned)c * (unsigned)ld), offJ = 8u * ((unsigned)(tj * BNR_GT + 2 * rp) + (unsigned)c * (unsigned)ld);
+    const unsigned offS = 8u * (unsigned)c;
+    // wave-uniform bases pinned to scalar registers: the loads below are "scalar base + constant 32-bit lane offset" and the loop carries no
+    // address VALU at all (round 5, tools/mfma_f64_mix.hip: every VALU instruction issued between f64 MFMAs takes 6-14 cycles from the
+    // matrix pipe, LDS / VMEM / SALU instructions and barriers take none; the loop used to carry 15 VALU instructions per 8 MFMAs)
+    const double *xb = bnr_sgpr_global(cd.X + (size_t)eb * ld);
+    const double *sb = bnr_sgpr_global(Sp + eb);       // S is followed by q_pad - q + 32 zeros in every trace row (bnr_chain_create): no clamp; X is zero there
     constexpr int PANEL = KB * BNR_GT;                 // doubles per panel (8 columns x 64 rows)
     double *stg = sred + (size_t)kg * (4 * PANEL);     // [buf][I|J][col][row ^ swizzle]
     const int woff = c * BNR_GT + ((2 * rp) ^ ((c & 1) << 4));
@@ -802,13 +828,13 @@ __device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const do
     bnr_d4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};   // c[jt][it]
     bnr_d2 ri, rj;
     double sv;
+    const __amdgpu_buffer_rsrc_t rX = bnr_rsrc(xb), rS = bnr_rsrc(sb);
+    const int bstep = KB * (int)ld * 8;                // bytes per batch (scalar)
 #define BNR_G8_LOAD(BIDX)                                                                    \
     do {                                                                                      \
-        const double *cb_ = xb + (size_t)(BIDX) * (KB * ld);                                  \
-        const int si_ = (BIDX) * KB + c;                                                      \
-        sv = sb[si_ < smax ? si_ : smax];                                                     \
-        ri = *(const bnr_d2 *)(cb_ + offI);                                                   \
-        rj = *(const bnr_d2 *)(cb_ + offJ);                                                   \
+        sv = bnr_bufload_f64(rS, offS, (BIDX) * (KB * 8));                                    \
+        ri = bnr_bufload_d2(rX, offI, (BIDX) * bstep);                                        \
+        rj = bnr_bufload_d2(rX, offJ, (BIDX) * bstep);                                        \
     } while (0)
 #define BNR_G8_STORE(BUF)                                                                     \
     do {                                                                                      \
@@ -842,18 +868,32 @@ __device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const do
         __syncthreads();                                                                      \
     } while (0)
 #define BNR_G8_BATCH(B) BNR_G8_BATCH_(B, false)
+    // two batches per trip with the buffer parity a literal: every LDS address is "lane base + immediate"
+#define BNR_G8_BATCH_L(B, PAR, DIAG)                                                          \
+    do {                                                                                      \
+        BNR_G8_COMPUTE(PAR, 0, DIAG);                                                         \
+        BNR_G8_STORE((PAR) ^ 1);                                                              \
+        BNR_G8_LOAD((B) + 2);                                                                 \
+        BNR_G8_COMPUTE(PAR, 1, DIAG);                                                         \
+        __syncthreads();                                                                      \
+    } while (0)
     if (BNR_GRAM_SKIP_DEAD && ti == tj && wi == 0 && wj == 1) {
         // dead block of a diagonal tile (see bnr_gram16_task): staging and barriers only, zeros out
-        for (int b = 0; b < nbatch; ++b) {
-            BNR_G8_STORE((b + 1) & 1);
-            BNR_G8_LOAD(b + 2);
-            __syncthreads();
+        int b = 0;
+        for (; b + 1 < nbatch; b += 2) {
+            BNR_G8_STORE(1); BNR_G8_LOAD(b + 2); __syncthreads();
+            BNR_G8_STORE(0); BNR_G8_LOAD(b + 3); __syncthreads();
         }
+        if (b < nbatch) { BNR_G8_STORE(1); BNR_G8_LOAD(b + 2); __syncthreads(); }
     } else if (BNR_GRAM_SKIP_DEAD && ti == tj && wi == wj) {
         // a diagonal 32 x 32 block: three MFMAs per k-step (see bnr_gram16_task)
-        for (int b = 0; b < nbatch; ++b) BNR_G8_BATCH_(b, true);
+        int b = 0;
+        for (; b + 1 < nbatch; b += 2) { BNR_G8_BATCH_L(b, 0, true); BNR_G8_BATCH_L(b + 1, 1, true); }
+        if (b < nbatch) BNR_G8_BATCH_L(b, 0, true);
     } else if (rot < 0) {
-        for (int b = 0; b < nbatch; ++b) BNR_G8_BATCH(b);
+        int b = 0;
+        for (; b + 1 < nbatch; b += 2) { BNR_G8_BATCH_L(b, 0, false); BNR_G8_BATCH_L(b + 1, 1, false); }
+        if (b < nbatch) BNR_G8_BATCH_L(b, 0, false);
     } else {
         // the same loop in chunks of 16 batches with the priority rotation between the chunks (kept out of the inner loop: a
         // branch in there changes how the compiler interleaves the MFMAs with the LDS reads)
