@@ -84,6 +84,7 @@ _SIGS = {
     "bnr_chain_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "bnr_chain_debug_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32]),
     "bnr_chain_debug_copy": (C.c_int, [C.c_void_p, C.c_int32, _dp, C.c_int64]),
+    "bnr_chain_debug_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "bnr_chain_debug_time_gram": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "bnr_debug_set_exp": (C.c_int, [C.c_int32, C.c_int32]),
     "bnr_host_philox": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -377,6 +378,23 @@ class Chain:
         out = np.empty(count)
         check(self.L.bnr_chain_debug_copy(self.h, which, _ptr(out), count))
         return out
+
+    def debug_dims(self):
+        out = (C.c_int32 * 8)()
+        check(self.L.bnr_chain_debug_dims(self.h, out))
+        return dict(zip(("n_pad", "q_pad", "ksplit", "ntile", "kcp", "kslab", "i8L", "rowlen"), [int(v) for v in out]))
+
+    def debug_gram(self):
+        """The (G) of the last Gram launch, lower triangle, summed over the K-split partial tiles on the host (diagnostics; n_pad x n_pad)."""
+        dm = self.debug_dims()
+        nt, ks = dm["ntile"], dm["ksplit"]
+        ntl = nt * (nt + 1) // 2
+        P = self.debug_copy(3, ks * ntl * 4096).reshape(ks, ntl, 64, 64).sum(axis=0)     # [tile][j][i]
+        G = np.zeros((dm["n_pad"], dm["n_pad"]))
+        for ti in range(nt):
+            for tj in range(ti + 1):
+                G[ti * 64:(ti + 1) * 64, tj * 64:(tj + 1) * 64] = P[ti * (ti + 1) // 2 + tj].T
+        return np.tril(G)
 
     def set_option(self, name, value):
         check(self.L.bnr_chain_set_option(self.h, name.encode(), int(value)))

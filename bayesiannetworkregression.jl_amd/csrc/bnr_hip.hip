@@ -113,6 +113,7 @@ struct bnr_chain {
     size_t trace_bytes = 0;
     struct bnr_group *group = nullptr;   // lockstep group this chain belongs to (at most one)
     const unsigned char *x8_kept = nullptr;   // the byte image of X (also while option "byte_x" is 0); nullptr: the input had none
+    const unsigned char *xm_kept = nullptr;   // the byte MASK of a 0/1 model matrix for the i8 Gram (also while option "gram_i8" is 0); nullptr: the input was not binary
     long long cap_seen = 0;      // sampler-cap events already reported (the device counter is cumulative: a capped draw is reported by the call it happened in, once)
 };
 
@@ -325,6 +326,10 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     }
     int kchunk = round_up((d.q + d.ksplit - 1) / d.ksplit, 8 * d.gram_kg);
     d.q_pad = kchunk * d.ksplit;
+    // the i8 Gram of a binary model matrix (k_gram_i8): K slices padded to whole 64-column MFMA steps, digit planes of S for 1e-12 of max |G|
+    d.kcp = round_up(kchunk, 64);
+    d.kslab = d.kcp * d.ksplit;
+    d.i8L = std::min(9, std::max(7, (int)std::ceil((std::log2((double)std::max(d.q, 2)) + 41.0) / 7.0)));
     // row layout
     int o = 4;
     d.o_xi = o; o += V;
@@ -354,7 +359,8 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     if (donor) {
         c->in = donor->in;
         c->x8_kept = donor->x8_kept;                     // the image belongs to the shared inputs: a chain made from a donor with byte_x = 0 can switch it on again
-        d.X = donor->d.X; d.X8 = donor->d.X8; d.y = donor->d.y; d.ek = donor->d.ek; d.el = donor->d.el; d.gmap = donor->d.gmap; d.gmapc = donor->d.gmapc;
+        c->xm_kept = donor->xm_kept;
+        d.X = donor->d.X; d.X8 = donor->d.X8; d.XM = donor->d.XM; d.y = donor->d.y; d.ek = donor->d.ek; d.el = donor->d.el; d.gmap = donor->d.gmap; d.gmapc = donor->d.gmapc;
     } else {
         c->in = std::make_shared<bnr_inputs>();
         double *Xd = nullptr, *yd = nullptr;
@@ -401,6 +407,29 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
         }
         d.X8 = X8;
         c->x8_kept = X8;
+        // every entry 0 or 1 (the reference's adjacency data): the row-major byte mask the i8 Gram reads, built from the byte image on the device
+        d.XM = nullptr;
+        {
+            const char *off8 = getenv("BNR_NO_GRAM_I8");
+            if (X8 && !(off8 && atoi(off8))) {
+                unsigned char *XM = nullptr;
+                int *nbin = nullptr;
+                TRY(in_alloc((void **)&XM, (size_t)d.n_pad * d.kslab));
+                TRY(in_alloc((void **)&nbin, sizeof(int)));
+                const size_t groups = (size_t)d.n_pad * (d.kslab / 16);
+                hipLaunchKernelGGL(k_x_mask, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->x.stream, (const unsigned char *)X8, d.n, d.n_pad, d.q, kchunk, d.kcp, d.kslab, XM, nbin);
+                int not_binary = 1;
+                if (hipStreamSynchronize(c->x.stream) != hipSuccess || hipMemcpy(&not_binary, nbin, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "building the byte mask of X failed"); }
+                if (not_binary) {
+                    auto it = std::find(c->in->bufs.begin(), c->in->bufs.end(), (void *)XM);
+                    if (it != c->in->bufs.end()) c->in->bufs.erase(it);
+                    (void)hipFree(XM);
+                    XM = nullptr;
+                }
+                d.XM = XM;
+            }
+        }
+        c->xm_kept = d.XM;
         {
             // XCD-aware task map of k_gram (tasks = lower tiles x K slices): workgroup i runs on XCD i % 8; give it a K
             // slice ks with ks % 8 == i % 8 while there are any, so that a slice of X is read through one XCD's L2
@@ -470,6 +499,7 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     TRY(dev_alloc(c, &d.bw, d.n_pad));
     TRY(dev_alloc(c, &d.wv, d.n_pad));
     TRY(dev_alloc(c, &d.scal, 16));
+    if (c->xm_kept) TRY(dev_alloc(c, &d.Sdig, (size_t)d.i8L * d.kslab));
     TRY(dev_alloc(c, &d.Minv, BNR_RMAX * BNR_RMAX + 1));
     TRY(dev_alloc(c, &d.Psum, (size_t)d.nblk_bp * (1 + 3 * R)));
     TRY(dev_alloc(c, &d.counters, 16));
@@ -717,6 +747,33 @@ static bool reduce_in_chol(const bnr_exec &x)
     const bool one_panel = x.factor_variant == 0 || (x.factor_variant < 0 && !two_panel_default(x));
     return one_panel && x.fuse_reduce != 0;
 }
+// the i8 Gram runs when every chain of the launch has the byte mask of a binary model matrix switched on (chain option "gram_i8")
+static bool gram_on_i8(const bnr_exec &x)
+{
+    if (x.nb == 1) return x.shape->XM != nullptr;
+    if (!x.cds_pin) return false;
+    for (int i = 0; i < x.nb; ++i)
+        if (!x.cds_pin[i].XM) return false;
+    return true;
+}
+#define BNR_LAUNCH_I8(LL)                                                                                                                   \
+    do {                                                                                                                                    \
+        const size_t lds = (size_t)(LL) * d.kcp;                                                                                            \
+        if (x.nb == 1) {                                                                                                                    \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sdigits<bnr_one, LL>), dim3(1), dim3(1024), 0, st, bnr_one{d}, s);                          \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram_i8<bnr_one, LL>), ggrid, dim3(256), lds, st, bnr_one{d}, s, 1);                        \
+        } else {                                                                                                                            \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sdigits<bnr_many, LL>), dim3(x.nb), dim3(1024), 0, st, bnr_many{x.cds}, s);                 \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram_i8<bnr_many, LL>), ggrid, dim3(256), lds, st, bnr_many{x.cds}, s, x.nb);               \
+        }                                                                                                                                   \
+    } while (0)
+static void launch_gram_i8(bnr_exec &x, int s, hipStream_t st, dim3 ggrid)
+{
+    const bnr_dev &d = *x.shape;
+    if (d.i8L == 7) BNR_LAUNCH_I8(7);
+    else if (d.i8L == 8) BNR_LAUNCH_I8(8);
+    else BNR_LAUNCH_I8(9);
+}
 static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
 {
     const bnr_dev &d = *x.shape;
@@ -734,6 +791,9 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
         HIPNOTE(hipEventRecord(e0, st));
     }
     const dim3 ggrid(round_up(ntl * d.ksplit, 8) * x.nb);
+    if (gram_on_i8(x) && x.gram_variant == 0) {
+        launch_gram_i8(x, s, st, ggrid);
+    } else
 #ifdef BNR_EXPERIMENTS
     if (x.gram_variant == 13 || (x.gram_variant == 0 && pipelined(x))) {
         // resident Gram that keeps off the reserved CUs; its queue heads are zeroed here, on the issuing stream (a memset node of the captured graph)
@@ -1657,7 +1717,8 @@ static int exec_last_timing(bnr_exec &x, int which, double *avg_us, int64_t *lau
     else if (which == 1) { *avg_us = x.t_gram_us; if (launches) *launches = x.n_gram; }
     else if (which == 2) { *avg_us = (double)x.n_eager; if (launches) *launches = x.n_replayed; }   // how the last run call was issued
     else if (which == 3) { *avg_us = x.shape->X8 ? 1.0 : 0.0; if (launches) *launches = x.shape->X8 ? 1 : 0; }   // do the X passes read a byte image of X
-    else return fail(BNR_ERR_BAD_ARG, "which must be 0, 1, 2 or 3");
+    else if (which == 4) { const bool on = gram_on_i8(x) && x.gram_variant == 0; *avg_us = on ? 1.0 : 0.0; if (launches) *launches = on ? x.shape->i8L : 0; }   // does the Gram run on the i8 matrix pipe (binary model matrix), with how many digit planes of S
+    else return fail(BNR_ERR_BAD_ARG, "which must be 0 .. 4");
     return BNR_OK;
 }
 // Replay both captured graphs ONCE on scratch rows, results discarded: the first replay of an instantiated graph pays for the
@@ -2442,10 +2503,24 @@ int bnr_chain_debug_copy(bnr_chain *c, int32_t which, double *out, int64_t count
     return BNR_OK;
 }
 
+int bnr_chain_debug_dims(bnr_chain *c, int32_t *out8)
+{
+    if (!c || !out8) return fail(BNR_ERR_BAD_ARG, "bad argument");
+    const bnr_dev &d = c->d;
+    const int v[8] = {d.n_pad, d.q_pad, d.ksplit, d.ntile, d.kcp, d.kslab, d.i8L, d.rowlen};
+    for (int i = 0; i < 8; ++i) out8[i] = v[i];
+    return BNR_OK;
+}
+
 static void launch_gram_only(bnr_chain *c)
 {
     const bnr_dev &d = c->d;
     const int ntl = d.ntile * (d.ntile + 1) / 2;
+    if (gram_on_i8(c->x) && c->x.gram_variant == 0) {
+        const dim3 ggrid(round_up(ntl * d.ksplit, 8));
+        launch_gram_i8(c->x, 0, c->x.stream, ggrid);
+        return;
+    }
 #ifdef BNR_EXPERIMENTS
     if (c->x.gram_variant == 11) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_one, 0>), dim3(3 * c->x.ncu), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1, c->x.gq);
     else if (c->x.gram_variant == 12) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_one, 1>), dim3(3 * c->x.ncu), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1, c->x.gq);
@@ -2509,6 +2584,16 @@ int bnr_chain_last_timing(bnr_chain *c, int32_t which, double *avg_us, int64_t *
 int bnr_chain_set_option(bnr_chain *c, const char *name, int64_t value)
 {
     if (!c || !name) return fail(BNR_ERR_BAD_ARG, "NULL argument");
+    if (!strcmp(name, "gram_i8")) {
+        // 1 (the default where the model matrix is binary): the Gram on the i8 matrix pipe; 0: the f64 Gram also for a binary matrix.  A matrix that
+        // is not binary has no i8 path: switching it on is refused.
+        if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");
+        if (value && !c->xm_kept) return fail(BNR_ERR_BAD_ARG, "gram_i8 needs a binary (0 / 1) integer-typed model matrix");
+        c->d.XM = value ? c->xm_kept : nullptr;
+        drop_graph(c->x);
+        if (c->group) drop_graph(c->group->x);
+        return sync_dev(c);
+    }
     if (!strcmp(name, "byte_x")) {
         // 0: the X passes read the f64 matrix also when a byte image exists; 1: back to the byte image (if the input had one)
         if (c->pending) return fail(BNR_ERR_BAD_ARG, "an asynchronous run is pending");

@@ -46,6 +46,11 @@ struct bnr_dev {
     const unsigned char *X8;     // X once more as BYTES (same padded layout) when the caller's model matrix is 0..255-valued (Bool adjacency
                                  // data, gibbs.jl:907-918): the two bandwidth-bound passes over X read an eighth of the bytes; nullptr otherwise
     const int *ek, *el;          // edge e -> column node k, row node l (l >= k)
+    // binary model matrix (every entry 0 or 1: the reference's adjacency data, docs/src/man/inputdata.md:5-10): the Gram on the i8 matrix pipe
+    const unsigned char *XM;     // [n_pad][kslab] row-major byte MASK of X (0xFF where X = 1): column k = ks kchunk + kk at byte ks kcp + kk of a row
+                                 // (every K slice padded with zeros to a multiple of 64 columns = one v_mfma_i32_16x16x64_i8 step); nullptr: no such image
+    unsigned char *Sdig;         // [i8L][kslab] the 7-bit digits of the chain's S in the same column order (k_sdigits), its scale in scal[SC_I8SCALE]
+    int kcp, kslab, i8L;         // padded K slice, bytes per row of XM, number of digit planes (7..9)
     // state
     double *trace;
     const bnr_plan_entry *plan;
@@ -88,7 +93,7 @@ struct bnr_dev {
 __device__ __forceinline__ bnr_dev bnr_globalized(const bnr_dev *src)
 {
     bnr_dev d = *src;
-    BNR_GLOBAL_PTR(X); BNR_GLOBAL_PTR(X8); BNR_GLOBAL_PTR(y); BNR_GLOBAL_PTR(ek); BNR_GLOBAL_PTR(el); BNR_GLOBAL_PTR(trace); BNR_GLOBAL_PTR(plan);
+    BNR_GLOBAL_PTR(X); BNR_GLOBAL_PTR(X8); BNR_GLOBAL_PTR(XM); BNR_GLOBAL_PTR(Sdig); BNR_GLOBAL_PTR(y); BNR_GLOBAL_PTR(ek); BNR_GLOBAL_PTR(el); BNR_GLOBAL_PTR(trace); BNR_GLOBAL_PTR(plan);
     BNR_GLOBAL_PTR(pbase); BNR_GLOBAL_PTR(Wbuf); BNR_GLOBAL_PTR(sz); BNR_GLOBAL_PTR(PW); BNR_GLOBAL_PTR(PA); BNR_GLOBAL_PTR(PG);
     BNR_GLOBAL_PTR(Gpart); BNR_GLOBAL_PTR(E); BNR_GLOBAL_PTR(gmap); BNR_GLOBAL_PTR(a3); BNR_GLOBAL_PTR(xw); BNR_GLOBAL_PTR(a4);
     BNR_GLOBAL_PTR(res); BNR_GLOBAL_PTR(xg); BNR_GLOBAL_PTR(bw); BNR_GLOBAL_PTR(wv); BNR_GLOBAL_PTR(scal); BNR_GLOBAL_PTR(Minv);
@@ -121,7 +126,7 @@ __device__ int bnr_exp_flags = 0;
 #define BNR_EXP_SKIP_CHOL(p) 0
 #endif
 enum { ROW_TAU2 = 0, ROW_THETA = 1, ROW_DELTA = 2, ROW_MU = 3 };
-enum { SC_RR = 0, SC_SIGQ = 1, SC_TAU = 2, SC_TAU2N = 3, SC_TAU2N_IT = 4 };   // TAU2N: tau2 pre-drawn by k_tail for iteration id TAU2N_IT
+enum { SC_RR = 0, SC_SIGQ = 1, SC_TAU = 2, SC_TAU2N = 3, SC_TAU2N_IT = 4, SC_I8SCALE = 8 };   // TAU2N: tau2 pre-drawn by k_tail for iteration id TAU2N_IT
 
 // ----------------------------------------------------------------------------------------- helpers
 // Sum over the 64 lanes of a wavefront, result in every lane.  Four DPP butterfly steps inside each row of 16 lanes
@@ -947,6 +952,135 @@ __global__ __launch_bounds__(512, 6) void k_gram8(const SRC chain_src, int s, in
 #ifdef BNR_EXPERIMENTS
     bnr_gram_epoch(cd, gslot);
 #endif
+}
+
+// ===================================================================================== the Gram of a BINARY model matrix on the i8 matrix pipe
+// (reference: docs/src/man/inputdata.md:5-10 -- the inputs are 0/1 adjacency data --, X_new = Matrix{eltype(T)} gibbs.jl:917, the
+// product Xtau tau2 D Xtau' of gibbs.jl:434.)  With x in {0, 1}:  G[i][j] = sum_k x_ik x_jk S_k.
+//   k_sdigits   S_k = sum_{l < L} d_l[k] 2^(e - 7 (l + 1)) + r_k,  d_l in 0..127,  2^e > max S,  0 <= r_k < 2^(e - 7 L)   (a 7 L-bit fixed point image
+//               of S under the exponent of its largest entry: entries far below the largest lose relative precision, G does not -- see the bound)
+//   k_gram_i8   T_l = X diag(d_l) X' EXACTLY in i32 (v_mfma_i32_16x16x64_i8; A = the byte mask of the j rows = -x, B = mask AND digits = x d of the
+//               i rows; |T_l| <= 127 kchunk), then G = - sum_l T_l 2^(e - 7 (l + 1)) by Horner in f64 (L roundings of relative size 2^-53).
+// Error against the exact Gram: 0 <= G_exact - G <= q 2^(e - 7 L) <= 2 q 2^(-7 L) max_k S_k, and max |G| >= max_k S_k as soon as the column of the largest S
+// has a one: relative to max |G| at most 2 q 2^(-7 L) -- L = ceil((log2 q + 41) / 7) (8 at q = 5050, 9 at q = 45150) keeps that below 1e-12, the size of the f64
+// path's own rounding.  Same tasks, K slices and partial-tile layout as k_gram8: the reduction in launch 0 of the factorization does not know the difference.
+// Measured (tools/gram_i8_lab.hip, profiles/round5_gram_i8.txt): 8 chains at n = 500, V = 100: 62 us per launch + 6 us for the digits against 192 us.
+__global__ void k_x_mask(const unsigned char *X8, int n, int n_pad, int q, int kchunk, int kcp, int kslab, unsigned char *XM, int *not_binary)
+{
+    // one thread per (row, 16-byte group) of XM; X8 is column-major (leading dimension n_pad): a one-off transpose at chain creation
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ng = kslab / 16;
+    if (idx >= (size_t)n_pad * ng) return;
+    const int i = (int)(idx / ng), g = (int)(idx % ng);
+    const int ks = (16 * g) / kcp, kk0 = (16 * g) % kcp;
+    bnr_i4 out = {0, 0, 0, 0};
+    bool bad = false;
+    for (int b = 0; b < 16; ++b) {
+        const int kk = kk0 + b, k = ks * kchunk + kk;
+        unsigned v = 0;
+        if (i < n && kk < kchunk && k < q) v = X8[(size_t)i + (size_t)n_pad * k];
+        if (v > 1u) bad = true;
+        if (v) out[b >> 2] |= 0xFF << (8 * (b & 3));
+    }
+    *(bnr_i4 *)(XM + (size_t)i * kslab + 16 * (size_t)g) = out;
+    if (bad) *not_binary = 1;
+}
+template <class SRC, int L>
+__global__ __launch_bounds__(1024) void k_sdigits(const SRC chain_src, int s)
+{
+    const bnr_dev &cd = chain_src.get_x();                    // grid = (chains)
+    const int tid = threadIdx.x;
+    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
+    const double *S = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
+    __shared__ double red[16];
+    double m = 0.0;
+    for (int k = tid; k < cd.q; k += 1024) m = fmax(m, S[k]);
+    m = fmax(m, __shfl_xor(m, 32)); m = fmax(m, __shfl_xor(m, 16)); m = fmax(m, __shfl_xor(m, 8));
+    m = fmax(m, __shfl_xor(m, 4)); m = fmax(m, __shfl_xor(m, 2)); m = fmax(m, __shfl_xor(m, 1));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = red[0];
+    for (int w = 1; w < 16; ++w) m = fmax(m, red[w]);
+    int e;
+    (void)frexp(m, &e);                                       // m = f 2^e with f in [0.5, 1): every S_k < 2^e
+    const double up = ldexp(1.0, 7 * L - e);                  // S_k up < 2^(7 L) <= 2^63
+    if (tid == 0) cd.scal[SC_I8SCALE] = ldexp(1.0, e - 7 * L);
+    const int kchunk = cd.q_pad / cd.ksplit;
+    for (int idx = tid; idx < cd.kslab; idx += 1024) {
+        const int ks = idx / cd.kcp, kk = idx % cd.kcp, k = ks * kchunk + kk;
+        unsigned long long N = 0;
+        if (kk < kchunk && k < cd.q) N = (unsigned long long)(S[k] * up);
+#pragma unroll
+        for (int l = 0; l < L; ++l) cd.Sdig[(size_t)l * cd.kslab + idx] = (unsigned char)((N >> (7 * (L - 1 - l))) & 127ull);
+    }
+}
+// one (tile, K slice) task per 256-thread workgroup: 2 x 2 waves of 32 x 32, each 2 x 2 MFMA blocks x L digit planes (16 L accumulator registers);
+// operands straight from L2 in fragment layout (16 consecutive bytes of a row per lane), the slice's digits in LDS (L x kcp bytes, dynamic)
+template <class SRC, int L>
+__global__ __launch_bounds__(256, 2) void k_gram_i8(const SRC chain_src, int s, int nchains)
+{
+    const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
+    const int gchain = gr % nchains, gslot = (gr / nchains) * 8 + gx;      // the task map of k_gram / k_gram8 (XCD-aware, chains of a group innermost)
+    const bnr_dev &cd = chain_src.at(gchain);
+    const int ntl = cd.ntile * (cd.ntile + 1) / 2;
+    if (gslot >= cd.ksplit * ntl) return;
+    const int task = cd.gmap[gslot];
+    int t = task & 0xFFFF, ti = 0;
+    const int ks = task >> 16;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    extern __shared__ bnr_i4 sDig[];                          // [l][kcp / 16]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ln = lane & 15, lq = lane >> 4;
+    const int wi = (wave >> 1) & 1, wj = wave & 1;
+    const int ng = cd.kcp / 16;
+    for (int idx = tid; idx < L * ng; idx += 256) {
+        const int l = idx / ng, g = idx % ng;
+        sDig[idx] = *(const bnr_i4 *)(cd.Sdig + (size_t)l * cd.kslab + (size_t)ks * cd.kcp + 16 * g);
+    }
+    __syncthreads();
+    const unsigned char *pa0 = cd.XM + (size_t)(tj * BNR_GT + wj * 32 + ln) * cd.kslab + (size_t)ks * cd.kcp + 16 * lq;     // j rows: A operand, the raw mask (= -x)
+    const unsigned char *pb0 = cd.XM + (size_t)(ti * BNR_GT + wi * 32 + ln) * cd.kslab + (size_t)ks * cd.kcp + 16 * lq;     // i rows: B operand, mask AND digit (= x d)
+    const size_t r16 = (size_t)16 * cd.kslab;
+    bnr_i4 acc[L][2][2];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[l][a][b] = bnr_i4{0, 0, 0, 0};
+    const int nstep = cd.kcp / 64;
+    bnr_i4 a0 = *(const bnr_i4 *)pa0, a1 = *(const bnr_i4 *)(pa0 + r16), b0 = *(const bnr_i4 *)pb0, b1 = *(const bnr_i4 *)(pb0 + r16);
+    for (int st = 0; st < nstep; ++st) {
+        bnr_i4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+        if (st + 1 < nstep) {
+            const int o = 64 * (st + 1);
+            na0 = *(const bnr_i4 *)(pa0 + o); na1 = *(const bnr_i4 *)(pa0 + r16 + o); nb0 = *(const bnr_i4 *)(pb0 + o); nb1 = *(const bnr_i4 *)(pb0 + r16 + o);
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const bnr_i4 dg = sDig[l * ng + st * 4 + lq];
+            const bnr_i4 m0 = b0 & dg, m1 = b1 & dg;
+            acc[l][0][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, m0, acc[l][0][0], 0, 0, 0);
+            acc[l][0][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, m1, acc[l][0][1], 0, 0, 0);
+            acc[l][1][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, m0, acc[l][1][0], 0, 0, 0);
+            acc[l][1][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, m1, acc[l][1][1], 0, 0, 0);
+        }
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+    // acc[l][jt][it][r]: j = wj 32 + jt 16 + 4 lq + r, i = wi 32 + it 16 + ln, holding -T_l (the A operand was -x); tile element (i, j) at [j 64 + i]
+    const double sc = -cd.scal[SC_I8SCALE];
+    double *out = cd.Gpart + ((size_t)ks * ntl + t) * (BNR_GT * BNR_GT);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = (double)acc[0][jt][it][r];
+#pragma unroll
+                for (int l = 1; l < L; ++l) v = v * 128.0 + (double)acc[l][jt][it][r];
+                out[(wj * 32 + jt * 16 + 4 * lq + r) * BNR_GT + wi * 32 + it * 16 + ln] = v * sc;
+            }
 }
 
 // E = extended matrix of the factorization, (2 n_pad + 32) x n_pad, column-major, leading dimension ldE:

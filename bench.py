@@ -53,6 +53,17 @@ print(done - 1, time.time() - t0, threads, mode, "|", blas or "")
 """
 
 
+def _measured_mfma_peak():
+    """TFLOP/s of a pure f64-MFMA loop on this chip, read from the committed microbenchmark output (never a literal)."""
+    import re
+    path = os.path.join(ROOT, "profiles", "round5_mfma_f64_peak.txt")
+    try:
+        vals = [float(m.group(1)) for line in open(path) if "(sustained)" in line for m in [re.search(r"([0-9.]+) TFLOP/s wall", line)] if m]
+        return float(sorted(vals)[len(vals) // 2]) if vals else None
+    except OSError:
+        return None
+
+
 def host_cpus():
     """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box shows all 256 hardware
     threads of its host, but its share per GPU is 16 cores -- oversubscribing spinning BLAS/OpenMP threads would understate the
@@ -431,7 +442,9 @@ def main():
                          "sweep_frac": sweep_tflops / FP64_MFMA_PEAK_TFLOPS, "sweep_achieved": sweep_tflops, "sweep_flops_per_chain_iteration": f_iter,
                          "flops_per_launch": flops_gram, "avg_launch_us": gram_us, "launches_timed": gram_n,
                          "avg_launch_us_two_branch_schedule": gram_us_pipe,
-                         "peak_measured_microbench": 70.0},
+                         "peak_measured_microbench": _measured_mfma_peak(),
+                         "peak_measured_source": "profiles/round5_mfma_f64_peak.txt (tools/mfma_f64_peak.hip: pure v_mfma_f64_16x16x4_f64 loop, census-checked, median of the lines marked sustained); "
+                                                 "under the Gram's real load (LDS + global traffic beside the MFMAs) the shader clock falls from 2.36-2.39 to 2.10 GHz: profiles/round5_gram_lab2_ablation.txt"},
             "max_rhat_gamma": None if rh is None else float(np.nanmax(rh[:q])), "max_rhat_xi": None if rh is None else float(np.nanmax(rh[q:])),
             "ess_gamma": None if ess is None else {"min": float(np.nanmin(ess[:q])), "median": float(np.nanmedian(ess[:q])),
                                                    "draws": int(nsamp * total_chains), "min_per_second": float(np.nanmin(ess[:q]) / dt)},

@@ -217,6 +217,7 @@ int bnr_chain_counters(bnr_chain *chain, int64_t out[8]);
 
 /* kernel timing: average device time in microseconds of the kernels of the last bnr_chain_run call, measured
  * with HIP events on the chain's own stream.  which: 0 = whole iteration, 1 = Gram kernel (X diag(S) X');
+ * (which = 3 / 4: is a byte image of X in use / does the Gram run on the i8 pipe, see bnr_chain_set_option.)
  * which = 2 reports how the last run call was issued: *launches = sweeps replayed from captured graphs, *avg_us = sweeps
  * launched eagerly (a steady-state run is all replay). */
 int bnr_chain_set_profiling(bnr_chain *chain, int32_t enable);
@@ -228,6 +229,10 @@ int bnr_chain_debug_read(bnr_chain *chain, uint64_t *out, int32_t count);
 int bnr_chain_debug_time_gram(bnr_chain *chain, int32_t reps, double *avg_us);
 /* diagnostics: copy an internal work buffer to the host (0 = factorization matrix E, 1 = rhs b, 2 = a4, 3 = Gram partials) */
 int bnr_chain_debug_copy(bnr_chain *chain, int32_t which, double *out, int64_t count);
+/* diagnostics: internal sizes {n_pad, q_pad, ksplit (K slices = planes of Gram partials), ntile (64-row tiles), kcp, kslab, i8L (i8 Gram: padded K slice,
+ * bytes per mask row, digit planes), rowlen (doubles per trace row on the device)}; the Gram partials of debug_copy(3) are [ksplit][ntile (ntile + 1) / 2][64 x 64],
+ * tile (ti >= tj) at index ti (ti + 1) / 2 + tj, element (i, j) of a tile at [j * 64 + i] */
+int bnr_chain_debug_dims(bnr_chain *chain, int32_t *out8);
 /* timing experiments: only a library built with -DBNR_EXPERIMENTS accepts it (the shipped one returns BNR_ERR_BAD_ARG).  flags bit 0: the
  * kernels of the scalar branch return at once (results are then NOT the sampler's) -- what the critical chain costs without company */
 int bnr_debug_set_exp(int32_t device, int32_t flags);
@@ -256,7 +261,14 @@ int bnr_debug_set_exp(int32_t device, int32_t flags);
  *               built with -DBNR_EXPERIMENTS (csrc/bnr_experiments.h, tools/r4_build_variants.sh); the shipped library refuses them by name.
  *   "byte_x"    (chains only) 0: the X passes read the f64 matrix although a byte image of X exists; 1 (default): the byte image
  *               (kept when the model matrix came as Bool/UInt8, or as Int32/Int64 with every value in 0..255; docs/src/man/inputdata.md)
- * All variants give the same tables bit for bit.  bnr_chain_last_timing(which = 3) says whether a byte image is in use. */
+ *   "gram_i8"   (chains only; round 5) 1 (default where it applies): the model matrix came integer-typed with every entry 0 or 1
+ *               (the reference's adjacency data, docs/src/man/inputdata.md:5-10) -- its Gram X diag(S) X' (gibbs.jl:434) runs on the i8 matrix pipe:
+ *               S as i8L = 7..9 planes of 7-bit digits under the exponent of its largest entry (k_sdigits), one exact i32 Gram per plane
+ *               (k_gram_i8, v_mfma_i32_16x16x64_i8), recombined in f64.  |G_i8 - G_exact| <= 2 q 2^(-7 i8L) max S <= 1e-12 max |G|; the tables
+ *               agree with the f64 Gram's to that size of perturbation (NOT bit for bit) and with the oracle to the same 1e-6 as everything
+ *               else.  0: the f64 Gram also for a binary matrix.  A matrix that is not binary has no i8 path (setting 1 is refused).
+ *               bnr_chain_last_timing(which = 4): *avg_us = 1 when the chain's (its group's) Gram runs on the i8 pipe, *launches = i8L.
+ * All variants except "gram_i8" give the same tables bit for bit.  bnr_chain_last_timing(which = 3) says whether a byte image is in use. */
 int bnr_chain_set_option(bnr_chain *chain, const char *name, int64_t value);
 
 /* Host-side copies of the draw-site primitives (same source as the device functions), exported so that the

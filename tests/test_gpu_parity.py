@@ -586,6 +586,17 @@ def test_input_formats_are_converted_on_the_device(gpu):
         ch = bnr_amd.Chain(bnr_amd.XInput(X, x_transform), y, R, tot, 11, 1)
         if bytes_expected is not None:                                                  # 0..255-valued integer input keeps a byte image of X
             assert (ch.last_timing(3)[1] == 1) == bytes_expected, (np.asarray(X[0]).dtype, x_transform)
+        # a 0/1 integer-typed matrix gets its Gram from the i8 matrix pipe by default (tested on its own below: close, not bitwise);
+        # THIS test is about the conversions, so every variant runs the f64 Gram
+        binary = bytes_expected is True and np.isin(np.asarray(bnr_amd.setup_X(X, True)[0] if x_transform else X), (0, 1)).all()
+        assert (ch.last_timing(4)[0] == 1) == bool(binary), (np.asarray(X[0]).dtype, x_transform)
+        if binary:
+            assert ch.last_timing(4)[1] in (7, 8, 9)
+            ch.set_option("gram_i8", 0)
+            assert ch.last_timing(4) == (0.0, 0)
+        else:
+            with pytest.raises(bnr_amd.BnrError):
+                ch.set_option("gram_i8", 1)
         ch.init_prior()
         ch.run(2, tot, tot)
         t = ch.fetch()
@@ -641,6 +652,7 @@ def test_byte_image_of_a_binary_model_matrix_at_config5_size(gpu):
             assert ch.last_timing(3)[1] == 1
             for c in (ch, mate):
                 c.set_option("byte_x", byte_x)
+                c.set_option("gram_i8", 0)                  # (the i8 Gram of a binary matrix is close, not bitwise: its own test below)
             assert ch.last_timing(3)[1] == byte_x
         else:
             assert ch.last_timing(3)[1] == 0
@@ -651,6 +663,7 @@ def test_byte_image_of_a_binary_model_matrix_at_config5_size(gpu):
         solo = bnr_amd.Chain.like(ch, 21, 1, tot)
         if byte_x is not None:
             solo.set_option("byte_x", byte_x)
+            solo.set_option("gram_i8", 0)
         solo.init_prior()
         solo.run(2, tot, tot)
         tabs = (ch.fetch(), solo.fetch())
@@ -669,6 +682,70 @@ def test_byte_image_of_a_binary_model_matrix_at_config5_size(gpu):
     o.init_prior()
     o.run(2, 3, 3)
     assert_tables_close({k: v[:3] for k, v in want.items()}, o.t, what="0/1 model matrix at config-5 size (byte image) vs oracle")
+
+
+@pytest.mark.parametrize("n,V,R,nmates", [(500, 300, 10, 2), (500, 100, 7, 7), (70, 19, 5, 1), (130, 40, 3, 0)])
+def test_binary_model_matrix_gram_on_the_i8_matrix_pipe(gpu, n, V, R, nmates):
+    """SURVEY 8f-2, second half (docs/src/man/inputdata.md:5-10: the inputs are 0/1 adjacency data; X_new = Matrix{eltype(T)} gibbs.jl:917;
+    the Gram Xtau tau2 D Xtau' of gibbs.jl:434): a Bool model matrix gets its Gram from v_mfma_i32_16x16x64_i8 -- S cut into i8L planes of
+    7-bit digits under a common exponent, one exact i32 Gram per plane, recombined in f64 (k_sdigits, k_gram_i8).  At BASELINE configs[4]'s
+    and configs[2]'s sizes, a small one and one whose n is no multiple of 64:
+      * G of the i8 path against G of the f64 path (same S): |dG| <= 1e-12 max |G|, the stated bound (the f64 path's own rounding);
+      * the tables against the ORACLE on the same 0/1 data: rtol 1e-6 like every other path;  against the f64-Gram tables: 1e-8;
+      * members of a lockstep group = the chain alone (bitwise: per layout the arithmetic is the same)."""
+    tot = 4
+    rng = np.random.default_rng(31 + n + V)
+    q = V * (V + 1) // 2
+    Xb = np.asfortranarray(rng.random((n, q)) < 0.5)
+    y = rng.normal(size=n)
+    tabs, grams = {}, {}
+    for mode in ("i8", "f64"):
+        ch = bnr_amd.Chain(bnr_amd.XInput(Xb, False), y, R, tot, 77, 1)
+        mates = [bnr_amd.Chain.like(ch, 77, 2 + m, tot) for m in range(nmates)]
+        assert ch.last_timing(4)[0] == 1 and ch.last_timing(4)[1] == ch.debug_dims()["i8L"]
+        if mode == "f64":
+            for c in [ch] + mates:
+                c.set_option("gram_i8", 0)
+            assert ch.last_timing(4) == (0.0, 0)
+        for c in [ch] + mates:
+            c.init_prior()
+        # ONE sweep alone first: the Gram of sweep 1 sees the prior draw's S in both modes
+        solo = bnr_amd.Chain.like(ch, 77, 1, tot)
+        if mode == "f64":
+            solo.set_option("gram_i8", 0)
+        solo.init_prior()
+        solo.run(2, tot, 2)
+        grams[mode] = solo.debug_gram()
+        solo.run(3, tot, tot)
+        if nmates:
+            g = bnr_amd.Group([ch] + mates)
+            assert g.last_timing(4)[0] == (1 if mode == "i8" else 0)
+            g.run(2, tot, tot)
+            t = ch.fetch()
+            one = bnr_amd.Chain.like(ch, 77, 1, tot)
+            if mode == "f64":
+                one.set_option("gram_i8", 0)
+            one.init_prior()
+            one.run(2, tot, tot)
+            ts = one.fetch()
+            one.close()
+            for k in bo.COLUMNS:
+                assert np.array_equal(t[k], ts[k]), (mode, "group member vs alone", k)
+            g.close()
+        tabs[mode] = solo.fetch()
+        assert solo.counters()["chol_fail"] == 0
+        for c in [ch, solo] + mates:
+            c.close()
+    gmax = np.abs(grams["f64"]).max()
+    err = np.abs(grams["i8"] - grams["f64"])[:n, :n].max() / gmax
+    assert err <= 1e-12, ("i8 Gram vs f64 Gram, relative to max |G|", err)
+    assert gmax > 0 and np.isfinite(grams["i8"]).all()
+    for k in bo.COLUMNS:
+        assert np.allclose(tabs["i8"][k], tabs["f64"][k], rtol=1e-8, atol=1e-11), ("i8-Gram tables vs f64-Gram tables", k, np.abs(tabs["i8"][k] - tabs["f64"][k]).max())
+    o = bo.Oracle(np.asfortranarray(Xb.astype(np.float64)), y, R, tot, 77, chain=1, pdf_mode=1)
+    o.init_prior()
+    o.run(2, tot, tot)
+    assert_tables_close(tabs["i8"], o.t, what="binary model matrix, Gram on the i8 pipe, vs oracle (n=%d V=%d)" % (n, V))
 
 
 def test_device_summary_equals_host_summary(gpu, test1):
