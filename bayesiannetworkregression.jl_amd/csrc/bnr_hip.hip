@@ -430,6 +430,9 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
             }
         }
         c->xm_kept = d.XM;
+        // default: on where it was measured faster (profiles/round5_gram_i8.txt: n = 500, V = 100 and larger -- 22 vs 35 us per launch for one chain, 70 vs 197 for
+        // eight; at n = 200, V = 50 the second launch costs more than the f64 Gram's 12 us).  Chain option "gram_i8" switches it either way.
+        if ((double)d.n_pad * d.n_pad * d.q < 2.5e8) d.XM = nullptr;
         {
             // XCD-aware task map of k_gram (tasks = lower tiles x K slices): workgroup i runs on XCD i % 8; give it a K
             // slice ks with ks % 8 == i % 8 while there are any, so that a slice of X is read through one XCD's L2

@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="0: single-stream schedule (diagnostics)")
     ap.add_argument("--graph-k", type=int, default=0, help="sweeps per captured graph (0: library default)")
     ap.add_argument("--graph", type=int, default=1, help="0: launch every kernel eagerly (diagnostics)")
+    ap.add_argument("--binary-x", action="store_true", help="NOT the headline: the same shape with a 0/1 model matrix given as Bool (the reference's adjacency inputs), whose Gram "
+                    "runs on the i8 matrix pipe (SURVEY 8f-2); the line says so in config.workload and roofline.kernel, dtype stays f64 (S, G and everything else are f64)")
     ap.add_argument("--dry-ranks", action="store_true", help="no GPU: every rank only reports which chains it would hold (checks the N-rank plumbing on a CPU)")
     a = ap.parse_args()
 
@@ -289,6 +291,8 @@ def main():
     n, V, R = cfg["n"], cfg["V"], cfg["R"]
     q = V * (V + 1) // 2
     X, y, _truth = bnr_amd.make_synthetic(n, V, R, seed=a.seed)
+    if a.binary_x:                                                # 0/1 adjacency-style data of the same shape, handed over as Bool (gibbs.jl:917: X_new keeps the element type)
+        X = bnr_amd.XInput(np.asfortranarray(np.random.default_rng(a.seed).random((n, q)) < 0.5), False)
     K, W = a.steps, a.warmup
     total_chains = world * a.chains_per_gpu if a.chains_per_gpu > 0 else a.chains
     tot = W + K + min(K, 200) + 1
@@ -421,7 +425,7 @@ def main():
         flops_gram = float(n) * n * q * C                         # algorithmic: symmetric X diag(S) X'  per chain of the launch
         traffic = None                                            # HBM bytes per k_gram launch from the PMC passes (tools/pmc_gram_round3.sh)
         pmc_file = os.path.join(ROOT, "profiles", "round4_gram_pmc.json")
-        if a.config == "cfg3" and C in (1, 8) and os.path.exists(pmc_file):
+        if a.config == "cfg3" and C in (1, 8) and not a.binary_x and os.path.exists(pmc_file):
             traffic = json.load(open(pmc_file))["default:k_gram<bnr_one,2>" if C == 1 else "default:k_gram8<bnr_many>"].get("traffic_bytes_per_launch")
         achieved = flops_gram / (gram_us * 1e-6) / 1e12 if gram_us > 0 else 0.0
         # whole-sweep roofline: F_iter = n^2 q + n^3/3 + 8 n q flops per chain-iteration, r = iterations/s per GPU
@@ -431,12 +435,14 @@ def main():
             "metric": "Gibbs iterations/sec (all chains)", "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
             "scaling": "weak" if a.chains_per_gpu > 0 else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic n=%d V=%d (q=%d) R=%d, %d chains total, %s per GPU" % (n, V, q, R, total_chains, C if total_chains % world == 0 else "%d or %d" % (total_chains // world, total_chains // world + 1))
+            "config": {"workload": ("synthetic n=%d V=%d (q=%d) R=%d, %d chains total, %s per GPU" % (n, V, q, R, total_chains, C if total_chains % world == 0 else "%d or %d" % (total_chains // world, total_chains // world + 1)))
+                                   + (" -- BINARY 0/1 model matrix given as Bool (--binary-x; not the headline workload): Gram on the i8 matrix pipe" if a.binary_x else "")
                                    + ("" if world == 1 else " (BASELINE configs[2]: the %d chains of the fit sharded round-robin over %d GPUs, chain c on rank (c-1) %% %d; "
                                       "the chains of a GPU advance as one lockstep group)" % (total_chains, world, world)),
                        "chains_total": total_chains, "chains_per_gpu": C, "seed": a.seed},
             "timed_region": {"sweeps_replayed_from_graphs": int(replayed_sweeps), "sweeps_launched_eagerly": int(eager_sweeps)},
-            "roofline": {"bound": "mfma", "kernel": "k_gram8 / k_gram (X diag(S) X', v_mfma_f64_16x16x4_f64)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": ("k_sdigits + k_gram_i8 (X diag(S) X' of a 0/1 X: i8L exact v_mfma_i32_16x16x64_i8 Grams recombined in f64; achieved / frac are the f64-equivalent "
+                                                      "algorithmic rate against the f64 peak, i.e. they may exceed 1)" if a.binary_x else "k_gram8 / k_gram (X diag(S) X', v_mfma_f64_16x16x4_f64)"), "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": "profiles/round4_gram_pmc.json (FETCH_SIZE x2 + WRITE_SIZE of a launch of this shape, separate --pmc passes, tools/pmc_gram_round4.sh)",
                          "sweep_frac": sweep_tflops / FP64_MFMA_PEAK_TFLOPS, "sweep_achieved": sweep_tflops, "sweep_flops_per_chain_iteration": f_iter,

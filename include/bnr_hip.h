@@ -261,7 +261,8 @@ int bnr_debug_set_exp(int32_t device, int32_t flags);
  *               built with -DBNR_EXPERIMENTS (csrc/bnr_experiments.h, tools/r4_build_variants.sh); the shipped library refuses them by name.
  *   "byte_x"    (chains only) 0: the X passes read the f64 matrix although a byte image of X exists; 1 (default): the byte image
  *               (kept when the model matrix came as Bool/UInt8, or as Int32/Int64 with every value in 0..255; docs/src/man/inputdata.md)
- *   "gram_i8"   (chains only; round 5) 1 (default where it applies): the model matrix came integer-typed with every entry 0 or 1
+ *   "gram_i8"   (chains only; round 5) 1 (the default from n_pad^2 q >= 2.5e8 on, where it was measured faster -- n = 500, V = 100 and
+ *               larger; smaller problems default to 0): the model matrix came integer-typed with every entry 0 or 1
  *               (the reference's adjacency data, docs/src/man/inputdata.md:5-10) -- its Gram X diag(S) X' (gibbs.jl:434) runs on the i8 matrix pipe:
  *               S as i8L = 7..9 planes of 7-bit digits under the exponent of its largest entry (k_sdigits), one exact i32 Gram per plane
  *               (k_gram_i8, v_mfma_i32_16x16x64_i8), recombined in f64.  |G_i8 - G_exact| <= 2 q 2^(-7 i8L) max S <= 1e-12 max |G|; the tables
