@@ -10,6 +10,7 @@ import numpy as np
 from ._build import LIB
 
 BNR_OK, BNR_ERR_BAD_ARG, BNR_ERR_HIP, BNR_ERR_CHOLESKY, BNR_ERR_SAMPLER = 0, 1, 2, 3, 4
+BNR_ERR_SAMPLER_CAP = BNR_ERR_SAMPLER
 ERRORS = {1: "bad argument", 2: "HIP error", 3: "Cholesky failed after jitter", 4: "sampler attempt cap"}
 
 

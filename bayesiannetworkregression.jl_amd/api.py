@@ -297,11 +297,25 @@ class ChainSet:
         """run! on every local chain (in lockstep when there are several).  The rank that holds chain 1 ticks the
         progress callback (gibbs.jl:854-856)."""
         cb = callback if 1 in self.ids else None
+
+        def tolerant(call):
+            # BNR_ERR_SAMPLER_CAP (4): a rejection sampler stopped at its attempt cap somewhere in this call.  Every row was written (with the
+            # capped draw's last proposal) and the table stays valid; the reference has no cap and never raises here.  A fit of 50 000
+            # iterations must not die of one such draw: warn once per call and go on -- counters()['sampler_cap'] keeps the total.
+            try:
+                call()
+            except _capi.BnrError as e:
+                if getattr(e, "code", None) == _capi.BNR_ERR_SAMPLER_CAP:
+                    import warnings
+                    warnings.warn("libbnr_hip: a rejection sampler hit its attempt cap during rows %d..%d (the rows were written; see counters()['sampler_cap'])" % (first_index, total), RuntimeWarning)
+                else:
+                    raise
+
         if self.group is not None:
-            self.group.run(first_index, nburn, total, purge_burn, prog_freq, cb)
+            tolerant(lambda: self.group.run(first_index, nburn, total, purge_burn, prog_freq, cb))
         else:
             for c in self.ids:
-                self.chains[c].run(first_index, nburn, total, purge_burn, prog_freq, cb if c == 1 else None)
+                tolerant(lambda c=c: self.chains[c].run(first_index, nburn, total, purge_burn, prog_freq, cb if c == 1 else None))
 
     def rhat(self, first_row, nsamp):
         """split-Rhat over ALL chains of the fit for gamma (q) then xi (V) (return_psrf_VOI, gibbs.jl:771-789)."""

@@ -47,12 +47,6 @@ struct bnr_exec {
     int pipeline = -1;                                  // -1: chosen by size / availability; 0: the factorization follows the Gram; 1: beside it
     int gate_us = 3000;                                 // how long a gate of the factorization polls for the Gram's progress
     unsigned *gctl = nullptr;                           // k_gram8p: queue heads and tickets
-#ifdef BNR_EXPERIMENTS
-    bnr_gramq gq{};                                     // k_gram8p: the per-XCD task lists inside gmapc (set by the owner from its inputs)
-    bnr_qent *qlist = nullptr;                          // k_gram8q: the per-XCD lists of (task, chain) entries of THIS exec (build_qlist), qq = their offsets
-    bnr_gramq qq{};
-    int qW = 0, q_for_mask = -1;                        // seats (CUs) of an XCD the resident Gram uses; the resv_mask the lists were built for
-#endif
     const unsigned *resv = nullptr;                     // reserved compute units (device table shared per device), nullptr: none
     std::vector<hipEvent_t> fj;                         // fork/join events
     size_t fj_next = 0;
@@ -155,11 +149,6 @@ static int ensure_lds_attributes(int device)
     const int big = 124 * 1024;
     const void *fns[] = {(const void *)&k_tail<bnr_one>, (const void *)&k_tail<bnr_many>, (const void *)&k_backproj<bnr_one>,
                          (const void *)&k_backproj<bnr_many>, (const void *)&k_solve_a4<bnr_one>, (const void *)&k_solve_a4<bnr_many>,
-#ifdef BNR_EXPERIMENTS
-                         (const void *)&k_chol_ll<bnr_one>, (const void *)&k_chol_ll<bnr_many>, (const void *)&k_chol_df<bnr_one>, (const void *)&k_chol_df<bnr_many>,
-                         (const void *)&k_chol_small<bnr_one, 4>, (const void *)&k_chol_small<bnr_many, 4>,
-                         (const void *)&k_gram_gate<bnr_one>, (const void *)&k_gram_gate<bnr_many>, (const void *)&k_backproj_group,
-#endif
                          (const void *)&k_xpass_group};
     for (const void *f : fns) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     done[device] = 1;
@@ -483,9 +472,6 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
         d.X = Xd; d.y = yd; d.ek = ek; d.el = el; d.gmap = gm; d.gmapc = gmc;
         for (int x = 0; x < 9; ++x) c->in->gq_off[x] = gq_off[x];
     }
-#ifdef BNR_EXPERIMENTS
-    for (int x = 0; x < 9; ++x) c->x.gq.qoff[x] = c->in->gq_off[x];
-#endif
     TRY(alloc_trace(c, tot_save, &d.trace));
     TRY(dev_alloc(c, &d.Wbuf, d.q_pad));
     TRY(dev_alloc(c, &d.sz, d.q_pad));
@@ -508,9 +494,6 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     TRY(dev_alloc(c, &d.counters, 16));
     TRY(dev_alloc(c, &d.stamp, 8 * ntl));
     TRY(dev_alloc(c, &d.gprog, d.ntile + 4));
-#ifdef BNR_EXPERIMENTS
-    TRY(dev_alloc(c, &d.dfctl, 32 + 32 * 16));
-#endif
     TRY(dev_alloc(c, &d.dbg, 4096));
     c->plan_cap = 1 << 16;
     TRY(dev_alloc(c, &c->plan_dev, c->plan_cap));
@@ -519,7 +502,9 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     if (hipHostMalloc((void **)&c->plan_pin, sizeof(bnr_plan_entry) * c->plan_cap) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipHostMalloc failed"); }
     if (hipHostMalloc((void **)&c->counters_host, sizeof(long long) * 16) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipHostMalloc failed"); }
     d.plan = c->plan_dev;
-    if (hipDeviceSynchronize() != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipDeviceSynchronize failed"); }   // every upload and fill above has landed, on whatever stream it ran
+    // every upload and fill above is either host-synchronous or on the chain's own stream: wait for THAT stream only (a device-wide synchronise would
+    // stall on another chain's or group's pending asynchronous run and could surface its errors here)
+    if (hipStreamSynchronize(c->x.stream) != hipSuccess) { bnr_chain_destroy(c); return fail(BNR_ERR_HIP, "hipStreamSynchronize failed"); }
     TRY(sync_dev(c));
     TRY(check_launch("chain_build"));                    // the index-map / task-map copies above only NOTE a failure: report it here, not in somebody's later call
 #undef TRY
@@ -563,10 +548,6 @@ static int exec_init(bnr_exec &x, int device, int nb, const bnr_dev *shape)
     }
     HIPCHK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&x.stream2, hipStreamNonBlocking));
-#ifdef BNR_EXPERIMENTS
-    HIPCHK(hipMalloc((void **)&x.gctl, sizeof(unsigned) * 8 * BNR_GQ_WORDS));
-    HIPCHK(hipMemsetAsync(x.gctl, 0, sizeof(unsigned) * 8 * BNR_GQ_WORDS, x.stream));
-#endif
     HIPCHK(hipMalloc((void **)&x.cds, sizeof(bnr_dev) * nb));
     HIPCHK(hipHostMalloc((void **)&x.cds_pin, sizeof(bnr_dev) * nb));
     HIPCHK(hipMalloc((void **)&x.status_dev, sizeof(long long) * 16 * nb));
@@ -581,9 +562,6 @@ static void exec_free(bnr_exec &x)
     if (x.stream4) { (void)hipStreamSynchronize(x.stream4); (void)hipStreamDestroy(x.stream4); }
     for (hipStream_t st : x.lstreams) { (void)hipStreamSynchronize(st); }
     if (x.gctl) (void)hipFree(x.gctl);
-#ifdef BNR_EXPERIMENTS
-    if (x.qlist) (void)hipFree(x.qlist);
-#endif
     drop_graph(x);
     for (hipStream_t st : x.lstreams) (void)hipStreamDestroy(st);
     x.lstreams.clear();
@@ -704,11 +682,7 @@ static void launch_xpass(bnr_exec &x, int s, int which)
 // run beside the Gram).  Same tables bit for bit.
 static bool left_looking(const bnr_exec &x)
 {
-#ifdef BNR_EXPERIMENTS
-    return x.factor_variant == 1;                        // opt-in: measured slower than right-looking in every schedule tried (notes round 3, B)
-#else
     (void)x; return false;
-#endif
 }
 // The sweep's schedule: pipelined (option "pipeline" = 1) = the factorization runs BESIDE the Gram (k_gram8p keeps off the reserved
 // CUs, k_chol_ll's gates follow its progress column by column); otherwise it follows the Gram on the same stream.
@@ -724,23 +698,13 @@ static bool two_panel_default(const bnr_exec &x) { return x.shape->n_pad >= 1024
 // (opt-in, experiments build only: bitwise the same factor, measured slower -- profiles/round4_experiments_notes.txt, F)
 static bool dataflow(const bnr_exec &x)
 {
-#ifdef BNR_EXPERIMENTS
-    if (x.shape->n_pad > 512 || x.nb > 8 || left_looking(x)) return false;
-    return x.factor_variant == 4;
-#else
     (void)x; return false;
-#endif
 }
 // small problems (n_pad <= 128): the whole factorization in ONE launch of one workgroup per chain (k_chol_small): factor_variant 5
 // (experiments build only: bitwise equal, measured slower -- profiles/round4_experiments_notes.txt H)
 static bool small_factor(const bnr_exec &x)
 {
-#ifdef BNR_EXPERIMENTS
-    if (x.shape->n_pad > 128 || left_looking(x)) return false;
-    return x.factor_variant == 5;
-#else
     (void)x; return false;
-#endif
 }
 // the one-panel right-looking factorization (k_chol_step) is the one that runs, and its first launch takes over k_gram_reduce's work
 static bool reduce_in_chol(const bnr_exec &x)
@@ -797,32 +761,6 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
     if (gram_on_i8(x) && x.gram_variant == 0) {
         launch_gram_i8(x, s, st, ggrid);
     } else
-#ifdef BNR_EXPERIMENTS
-    if (x.gram_variant == 13 || (x.gram_variant == 0 && pipelined(x))) {
-        // resident Gram that keeps off the reserved CUs; its queue heads are zeroed here, on the issuing stream (a memset node of the captured graph)
-        hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(1024), 0, st, x.gctl, 8 * BNR_GQ_WORDS);
-        const dim3 qgrid(3 * x.ncu);
-        const unsigned mask = (unsigned)x.resv_mask;
-        if (!x.qlist) { g_noted = hipErrorInvalidValue; g_noted_what = "k_gram8q without its work lists (build_qlist)"; return; }
-        if (pipelined(x)) {
-            if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8q<bnr_one, true>), qgrid, dim3(512), 0, st, bnr_one{d}, s, (const bnr_qent *)x.qlist, x.qq, mask, x.gctl, x.qW);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8q<bnr_many, true>), qgrid, dim3(512), 0, st, bnr_many{x.cds}, s, (const bnr_qent *)x.qlist, x.qq, mask, x.gctl, x.qW);
-        } else {
-            if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8q<bnr_one, false>), qgrid, dim3(512), 0, st, bnr_one{d}, s, (const bnr_qent *)x.qlist, x.qq, mask, x.gctl, x.qW);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8q<bnr_many, false>), qgrid, dim3(512), 0, st, bnr_many{x.cds}, s, (const bnr_qent *)x.qlist, x.qq, mask, x.gctl, x.qW);
-        }
-    } else if (x.gram_variant == 9) {
-        const unsigned *resv = nullptr;
-        const dim3 pgrid(BNR_G8P_WPC * x.ncu);
-        if (resv) {
-            if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_one, true>), pgrid, dim3(512), 0, st, bnr_one{d}, s, 1, x.gq, resv, x.gctl);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_many, true>), pgrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb, x.gq, resv, x.gctl);
-        } else {
-            if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_one, false>), pgrid, dim3(512), 0, st, bnr_one{d}, s, 1, x.gq, resv, x.gctl);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_many, false>), pgrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb, x.gq, resv, x.gctl);
-        }
-    } else
-#endif
     if (d.gram_kg == 4) {
         if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), ggrid, dim3(1024), 0, st, bnr_one{d}, s, 1);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_many, 4>), ggrid, dim3(1024), 0, st, bnr_many{x.cds}, s, x.nb);
@@ -833,24 +771,6 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
         // workgroups than two per CU.  A launch that fits in one round (one chain: 252 workgroups at the headline size) never reaches
         // that occupancy and is better off with k_gram's 16-column batches = half the barriers (33.5 vs 36.0 us; n=500, V=300: 228 vs 237).
         const bool wide = x.gram_variant ? x.gram_variant == 16 : ((long)x.nb * ntl * d.ksplit <= 2L * x.ncu);
-#ifdef BNR_EXPERIMENTS
-        if (x.gram_variant == 11 || x.gram_variant == 12 || x.gram_variant == 14) {   // one resident round, static task loop (12: with the priority rotation; 14: in queue order)
-            const dim3 sgrid(3 * x.ncu);
-            if (x.gram_variant == 11) {
-                if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_one, 0>), sgrid, dim3(512), 0, st, bnr_one{d}, s, 1, x.gq);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_many, 0>), sgrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb, x.gq);
-            } else if (x.gram_variant == 14) {
-                if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_one, 2>), sgrid, dim3(512), 0, st, bnr_one{d}, s, 1, x.gq);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_many, 2>), sgrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb, x.gq);
-            } else {
-                if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_one, 1>), sgrid, dim3(512), 0, st, bnr_one{d}, s, 1, x.gq);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_many, 1>), sgrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb, x.gq);
-            }
-        } else if (x.gram_variant == 10) {                        // experiment: the unscaled panel by LDS-DMA
-            if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8d<bnr_one>), ggrid, dim3(512), 0, st, bnr_one{d}, s, 1);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8d<bnr_many>), ggrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb);
-        } else
-#endif
         if (!wide) {
             if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8<bnr_one>), ggrid, dim3(512), 0, st, bnr_one{d}, s, 1);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8<bnr_many>), ggrid, dim3(512), 0, st, bnr_many{x.cds}, s, x.nb);
@@ -862,103 +782,13 @@ static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
     if (timed) HIPNOTE(hipEventRecord(e1, st));
     if (!left_looking(x) && !reduce_in_chol(x)) BNR_LAUNCH(k_gram_reduce, dim3(ntl, 8, x.nb), dim3(256), 0, st, x, s);
 }
-#ifdef BNR_EXPERIMENTS
-// k_gram8q's work lists (see the kernel): for every XCD a list of (tile | K slice << 16, chain) entries in tile-COLUMN order, all of
-// (nearly) the same length.  XCD x gets the K slices ks = x mod 8 (one slice of X per L2); XCDs that would hold more than an eighth of
-// the entries give whole tasks (all chains of a tile and slice: they share its panels of X), evenly spaced over the columns, to those that
-// hold less.  Built once per exec and reservation mask, outside any stream capture.
-static int build_qlist(bnr_exec &x)
-{
-    if (x.qlist && x.q_for_mask == x.resv_mask) return BNR_OK;
-    const bnr_dev &d = *x.shape;
-    const int nb = x.nb, ntile = d.ntile;
-    struct unit { int task, c0, c1, col; };
-    std::vector<std::vector<unit>> bucket(8);
-    for (int tc = 0; tc < ntile; ++tc)
-        for (int ti = tc; ti < ntile; ++ti)
-            for (int ks = 0; ks < d.ksplit; ++ks) bucket[ks % 8].push_back(unit{(ti * (ti + 1) / 2 + tc) | (ks << 16), 0, nb, tc});
-    const long total = (long)ntile * (ntile + 1) / 2 * d.ksplit * nb;
-    const long T = (total + 7) / 8;
-    auto entries = [](const std::vector<unit> &v) { long n = 0; for (const unit &u : v) n += u.c1 - u.c0; return n; };
-    std::vector<unit> pool;
-    for (int b = 0; b < 8; ++b) {
-        long excess = entries(bucket[b]) - T;
-        if (excess <= 0) continue;
-        const int ngive = (int)((excess + nb - 1) / nb), ntask = (int)bucket[b].size();
-        std::vector<char> give(ntask, 0);
-        for (int k = 0; k < ngive; ++k) give[std::min(ntask - 1, (int)(((2L * k + 1) * ntask) / (2L * ngive)))] = 1;
-        std::vector<unit> keep;
-        for (int i = 0; i < ntask; ++i) {
-            unit u = bucket[b][i];
-            if (give[i] && excess > 0) {
-                const int g = (int)std::min<long>(excess, nb);          // the last one may be a part of a task: its first g chains go, the others stay
-                pool.push_back(unit{u.task, 0, g, u.col});
-                if (g < nb) keep.push_back(unit{u.task, g, nb, u.col});
-                excess -= g;
-            } else keep.push_back(u);
-        }
-        bucket[b] = keep;
-    }
-    // deal the pool to the lists that are short, a unit at a time (split where it does not fit)
-    size_t pi = 0;
-    while (pi < pool.size()) {
-        bool moved = false;
-        for (int b = 0; b < 8 && pi < pool.size(); ++b) {
-            long need = T - entries(bucket[b]);
-            if (need <= 0) continue;
-            unit &u = pool[pi];
-            const int g = (int)std::min<long>(need, u.c1 - u.c0);
-            bucket[b].push_back(unit{u.task, u.c0, u.c0 + g, u.col});
-            u.c0 += g;
-            if (u.c0 >= u.c1) ++pi;
-            moved = true;
-        }
-        if (!moved) return fail(BNR_ERR_BAD_ARG, "internal: the Gram work lists do not balance");
-    }
-    std::vector<bnr_qent> flat;
-    for (int b = 0; b < 8; ++b) {
-        std::stable_sort(bucket[b].begin(), bucket[b].end(), [](const unit &a, const unit &c) { return a.col < c.col; });
-        x.qq.qoff[b] = (int)flat.size();
-        for (const unit &u : bucket[b]) for (int c = u.c0; c < u.c1; ++c) flat.push_back(bnr_qent{u.task, c});
-    }
-    x.qq.qoff[8] = (int)flat.size();
-    if ((long)flat.size() != total) return fail(BNR_ERR_BAD_ARG, "internal: the Gram work lists lost entries");
-    HIPCHK(hipSetDevice(x.device));
-    if (x.qlist) { HIPCHK(hipStreamSynchronize(x.stream)); (void)hipFree(x.qlist); x.qlist = nullptr; }
-    HIPCHK(hipMalloc((void **)&x.qlist, sizeof(bnr_qent) * std::max<size_t>(flat.size(), 1)));
-    HIPCHK(hipMemcpyAsync(x.qlist, flat.data(), sizeof(bnr_qent) * flat.size(), hipMemcpyHostToDevice, x.stream));
-    HIPCHK(hipStreamSynchronize(x.stream));
-    x.qW = std::max(1, std::min(BNR_GQ_WORDS - 65, x.ncu / 8 - 4 * __builtin_popcount((unsigned)x.resv_mask)));   // seats = CUs of an XCD the Gram may use
-    x.q_for_mask = x.resv_mask;
-    return BNR_OK;
-}
-#else
 static int build_qlist(bnr_exec &) { return BNR_OK; }
-#endif
 static bool wants_qlist(const bnr_exec &x);
-#ifdef BNR_EXPERIMENTS
-static bool wants_qlist(const bnr_exec &x) { return x.gram_variant == 13 || (x.gram_variant == 0 && pipelined(x)); }
-#else
 static bool wants_qlist(const bnr_exec &) { return false; }
-#endif
 static void launch_rhs(bnr_exec &x, int s) { BNR_LAUNCH(k_rhs, dim3(x.shape->n_pad / 64, 1, x.nb), dim3(256), 0, x.stream, x, s); }
 static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
 {
     const int nbk = x.shape->n_pad / BNR_NB;
-#ifdef BNR_EXPERIMENTS
-    if (small_factor(x)) {
-        const size_t lds = (size_t)nbk * sizeof(bnr_panel_lds);
-        if (x.nb == 1) {
-            if (nbk == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_small<bnr_one, 2>), dim3(1), dim3(512), lds, st, bnr_one{*x.shape}, s);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_small<bnr_one, 4>), dim3(1), dim3(1024), lds, st, bnr_one{*x.shape}, s);
-        } else {
-            if (nbk == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_small<bnr_many, 2>), dim3(x.nb), dim3(512), lds, st, bnr_many{x.cds}, s);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_small<bnr_many, 4>), dim3(x.nb), dim3(1024), lds, st, bnr_many{x.cds}, s);
-        }
-        return;
-    }
-    if (dataflow(x)) { BNR_LAUNCH(k_chol_df, dim3(8 * BNR_DF_WG), dim3(256), BNR_DF_LDS, st, x, s, x.nb); return; }
-#endif
     if (x.factor_variant == 2 || x.factor_variant == 3 || (x.factor_variant < 0 && two_panel_default(x))) {
         // two panels per launch (k_chol_step2): half the launches on the critical path, the same arithmetic; variant 3 (the choice for
         // large n): the whole trailing matrix is read and written at every other launch only, with K = 128
@@ -970,16 +800,7 @@ static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
         }
         return;
     }
-#ifdef BNR_EXPERIMENTS
-    if (left_looking(x)) {
-        const int nA = (nbk + 3) / 4, nB = nbk - 1;
-        for (int p = 0; p < nbk; ++p)
-            BNR_LAUNCH(k_chol_ll, dim3(x.nb, nA + (p + 1 < nbk ? nB : 0)), dim3(256), BNR_LL_LDS, st, x, p, s, nA, spin_us);
-        return;
-    }
-#else
     (void)spin_us;
-#endif
     // update workgroups: one 32 x 32 block each while panels + updates of all members fit the chip in one round (two 256-thread
     // workgroups per CU); otherwise (large n, groups) 64 x 64 super blocks
     const int ncu = x.ncu, fuse0 = reduce_in_chol(x) ? 1 : 0;
@@ -1013,17 +834,6 @@ static void launch_solve(bnr_exec &x)
 static void launch_backproj(bnr_exec &x, int s, int flags)
 {
     size_t lds = std::max<size_t>(x.shape->n_pad + 64, (size_t)(3 * x.shape->R + 1) * 33) * sizeof(double);
-#ifdef BNR_EXPERIMENTS
-    if (flags == 7 && x.group_backproj == 1 && group_shares_x(x)) {
-        // one workgroup per block of 32 edges for BNR_BPG_CT members: X read once per tile of members, four speculative attempts per draw
-        const int R = x.shape->R, SA = std::max(std::max(x.shape->n_pad, (3 * R + 1) * 33), 32 * 22);
-        const size_t glds = (size_t)BNR_BPG_CT * (SA + 33 * R + 32) * sizeof(double);
-        if (glds <= 120 * 1024) {
-            hipLaunchKernelGGL(k_backproj_group, dim3(x.shape->nblk_bp, (x.nb + BNR_BPG_CT - 1) / BNR_BPG_CT), dim3(64 * BNR_BPG_CT * BNR_BPG_WPC), glds, x.stream, bnr_many{x.cds}, s, x.nb);
-            return;
-        }
-    }
-#endif
     const int nslot = (x.nb * x.shape->nblk_bp <= 2 * x.ncu) ? 8 : 2;    // speculative GIG attempts per edge and round
     BNR_LAUNCH(k_backproj, dim3(round_up(x.shape->nblk_bp, 8) * x.nb), dim3(256), lds, x.stream, x, s, flags, x.nb, nslot);
 }
@@ -1068,65 +878,10 @@ static void launch_sweep(bnr_exec &x, int s, bool prev_tail)
     hipStream_t sb = overlap ? x.stream2 : x.stream;
     const bool pipe = pipelined(x);
     hipEvent_t ej[3] = {nullptr, nullptr, nullptr};
-#ifdef BNR_EXPERIMENTS
-    if (pipe) {
-        // branch B: the Gram (persistent, off the reserved CUs); branch C: the factorization, gated on the Gram's progress; and in front
-        // of both a branch of one empty kernel: hipGraph runs the FIRST-captured forked branch to its end before it starts any other
-        // (profiles/round3_experiments_notes.txt A.3), so the first one must be nothing
-        hipEvent_t ef = next_event(x);
-        HIPNOTE(hipEventRecord(ef, x.stream));
-        HIPNOTE(hipStreamWaitEvent(x.stream4, ef, 0));
-        hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, x.stream4);
-        HIPNOTE(hipEventRecord(ej[0] = next_event(x), x.stream4));
-        HIPNOTE(hipStreamWaitEvent(x.stream2, ef, 0));
-        launch_gram(x, s, x.stream2, timed);
-        HIPNOTE(hipEventRecord(ej[1] = next_event(x), x.stream2));
-        HIPNOTE(hipStreamWaitEvent(x.stream3, ef, 0));
-        BNR_LAUNCH(k_gram_gate, dim3(x.nb), dim3(64), 72 * 1024, x.stream3, x, 0, x.gate_us);
-        launch_chol(x, s, x.stream3, x.gate_us);
-        HIPNOTE(hipEventRecord(ej[2] = next_event(x), x.stream3));
-    } else if (overlap && x.crit_origin) {
-        // the scalar branch is the forked one: the critical chain never changes queue (a kernel whose predecessor sits on another queue
-        // starts ~5 us late, profiles/round3_timeline_default.txt: chol step 15 -> solve, back-projection -> Gram)
-        hipEvent_t ef = next_event(x);
-        HIPNOTE(hipEventRecord(ef, x.stream));
-        hipEvent_t e4 = nullptr;
-        if (x.crit_origin == 2 && x.stream4) {
-            HIPNOTE(hipStreamWaitEvent(x.stream4, ef, 0));
-            hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, x.stream4);
-            HIPNOTE(hipEventRecord(e4 = next_event(x), x.stream4));
-        }
-        HIPNOTE(hipStreamWaitEvent(x.stream2, ef, 0));
-        std::swap(x.stream, x.stream2);                    // the launch helpers of the scalar branch issue on x.stream
-        if (prev_tail) launch_full_tail(x, s - 1);
-        launch_node(x, s, 3);
-        launch_xpass(x, s, 3);
-        launch_rhs(x, s);
-        hipEvent_t es = next_event(x);
-        HIPNOTE(hipEventRecord(es, x.stream));
-        std::swap(x.stream, x.stream2);
-        launch_gram(x, s, x.stream, timed);
-        launch_chol(x, s, x.stream);
-        HIPNOTE(hipStreamWaitEvent(x.stream, es, 0));
-        if (e4) HIPNOTE(hipStreamWaitEvent(x.stream, e4, 0));
-        launch_solve(x);
-        launch_backproj(x, s, split_sums(x) ? 3 : 7);
-        return;
-    } else
-#else
     (void)pipe;
-#endif
     if (overlap) {
         hipEvent_t ef = next_event(x);
         HIPNOTE(hipEventRecord(ef, x.stream));
-#ifdef BNR_EXPERIMENTS
-        if (x.nop_fork && x.stream4) {
-            // an empty kernel as the FIRST-captured forked branch: a captured graph treats its first fork specially (notes r3 A.3, r4 F)
-            HIPNOTE(hipStreamWaitEvent(x.stream4, ef, 0));
-            hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, x.stream4);
-            HIPNOTE(hipEventRecord(ej[1] = next_event(x), x.stream4));
-        }
-#endif
         HIPNOTE(hipStreamWaitEvent(x.stream2, ef, 0));
         launch_gram(x, s, sb, timed);
         launch_chol(x, s, sb);
@@ -1155,105 +910,6 @@ static int collect_gram_times(bnr_exec &x, int nsweeps)
     return BNR_OK;
 }
 
-#ifdef BNR_EXPERIMENTS
-// ---------------------------------------------------------------------------------------------------------- linear schedule
-// The members of a group as `lin` parts (1, 2 or 4), every part with two streams -- C: ring gate, Gram, factorization, gate, solve,
-// back-projection; S: gate, the scalar branch -- and every stream replaying LINEAR graphs.  The parts are phase-shifted by a ring of
-// counters: part p's Gram of a sweep waits for part p-1's (part 0's for the last part's of the sweep before), so the matrix cores always
-// have exactly one Gram to run and every part's latency chains run beside the OTHER parts' Grams.  A chain's arithmetic does not depend
-// on who shares its launches: bitwise the same tables.
-//   lflags (device, unsigned long long): [0] sticky; [1] ring = Grams finished; per part p at 8 + 8 p: [0] back-projections finished, [1] rhs
-//   finished, [2] sweeps the C stream's graphs have advanced over, [3] the same for the S stream.
-static bnr_exec part_view(const bnr_exec &x, int first, int count, hipStream_t st)
-{
-    bnr_exec v = x;                                          // shallow: the view owns nothing
-    v.cds = x.cds + first; v.cds_pin = x.cds_pin + first; v.nb = count; v.stream = st;
-    v.ladder.clear(); v.fj.clear(); v.ev.clear(); v.lstreams.clear(); v.lladder.clear();
-    return v;
-}
-static void lin_parts(const bnr_exec &x, std::vector<int> &first)
-{
-    const int P = x.lin;
-    first.assign(P + 1, 0);
-    for (int p = 0; p < P; ++p) first[p + 1] = first[p] + (x.nb / P) + (p < x.nb % P ? 1 : 0);
-}
-static int capture_linear(bnr_exec &x, int K, int p, int which, hipGraph_t *graph, hipGraphExec_t *gexec)
-{
-    std::vector<int> first;
-    lin_parts(x, first);
-    const int P = x.lin, nbp = first[p + 1] - first[p];
-    hipStream_t st = x.lstreams[x.lin_merge ? p : 2 * p + which];
-    unsigned long long *lf = x.lflags, *pf = x.lflags + 8 + 8 * p;
-    long long *err = x.shape->counters + 8;
-    unsigned long long *dbg = x.lin_debug ? x.shape->dbg : nullptr;       // member 0's diagnostics buffer
-    bnr_exec v = part_view(x, first[p], nbp, st);
-    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    for (int s = 0; s < K; ++s) {
-        if (which == 1) {
-            // S: the scalar branch, behind the part's back-projection of the sweep before
-            hipLaunchKernelGGL(k_lin_gate, dim3(1), dim3(64), 0, st, pf + 0, pf + 3, s, 1, 0, x.gate_us, lf, err, dbg, p, 0);
-            launch_full_tail(v, s - 1);
-            launch_node(v, s, 3);
-            launch_xpass(v, s, 3);
-            launch_rhs(v, s);
-            hipLaunchKernelGGL(k_lin_set, dim3(1), dim3(64), 0, st, pf + 1, pf + 3, s, 1, 1, dbg, p, 1);
-        } else {
-            if (x.lin_merge) {
-                // one stream per part: its scalar branch in front of its Gram (the other parts' work runs beside both)
-                launch_full_tail(v, s - 1);
-                launch_node(v, s, 3);
-                launch_xpass(v, s, 3);
-                launch_rhs(v, s);
-            }
-            // C: the Gram takes its turn in the ring, then the part's latency chain
-            if (P > 1) hipLaunchKernelGGL(k_lin_gate, dim3(1), dim3(64), 0, st, lf + 1, pf + 2, s, P, p, x.gate_us, lf, err, dbg, p, 2);
-            launch_gram(v, s, st, false);
-            if (P > 1) hipLaunchKernelGGL(k_lin_set, dim3(1), dim3(64), 0, st, lf + 1, pf + 2, s, P, p + 1, dbg, p, 3);
-            launch_chol(v, s, st);
-            if (!x.lin_merge) hipLaunchKernelGGL(k_lin_gate, dim3(1), dim3(64), 0, st, pf + 1, pf + 2, s, 1, 1, x.gate_us, lf, err, dbg, p, 4);
-            launch_solve(v);
-            launch_backproj(v, s, split_sums(v) ? 3 : 7);
-            if (s == K - 1) hipLaunchKernelGGL(k_advance, dim3(nbp), dim3(1), 0, st, (const bnr_dev *)v.cds, K);   // before the hand-over: the S stream's next tail finds the new base
-            if (!x.lin_merge || dbg) hipLaunchKernelGGL(k_lin_set, dim3(1), dim3(64), 0, st, pf + 0, pf + 2, s, 1, 1, dbg, p, 5);
-        }
-    }
-    hipLaunchKernelGGL(k_lin_add, dim3(1), dim3(64), 0, st, pf + 2 + which, K);
-    HIPCHK(hipStreamEndCapture(st, graph));
-    HIPCHK(hipGraphInstantiate(gexec, *graph, nullptr, nullptr, 0));
-    (void)hipGraphUpload(*gexec, st);
-    (void)hipGetLastError();
-    return BNR_OK;
-}
-static bool linear_mode(const bnr_exec &x) { return x.lin >= 1 && x.nb >= x.lin && x.use_graph && !x.profiling && x.overlap && !x.lstreams.empty() && x.lflags; }
-static int linear_prepare(bnr_exec &x)
-{
-    if (!x.lladder.empty()) return BNR_OK;
-    for (int k = x.graph_k; k >= 1; k /= 2) {
-        for (int p = 0; p < x.lin; ++p)
-            for (int w = 0; w < (x.lin_merge ? 1 : 2); ++w) {
-                bnr_exec::lrung r{k, p, w, nullptr, nullptr};
-                int rc = capture_linear(x, k, p, w, &r.graph, &r.gexec);
-                x.lladder.push_back(r);
-                if (rc) { drop_graph(x); return rc; }
-            }
-    }
-    return BNR_OK;
-}
-// enqueue `count` sweeps on the 2 lin streams; the caller has made them wait for x.stream and joins them afterwards
-static int linear_range(bnr_exec &x, int count)
-{
-    int rc = linear_prepare(x);
-    if (rc) return rc;
-    std::vector<int> ks;
-    int done = 0;
-    for (int k = x.graph_k; k >= 1; k /= 2) while (count - done >= k) { ks.push_back(k); done += k; }
-    for (auto it = ks.rbegin(); it != ks.rend(); ++it)
-        for (const auto &r : x.lladder)
-            if (r.k == *it) HIPCHK(hipGraphLaunch(r.gexec, x.lstreams[x.lin_merge ? r.part : 2 * r.part + r.which]));
-    x.n_replayed += count;
-    return BNR_OK;
-}
-#endif
 // Capture K sweeps (+ the plan-base advance) into a graph and instantiate it.  The kernels find their plan entry through
 // pbase at run time, so a captured graph serves every later batch.
 static int capture_sweeps(bnr_exec &x, int K, hipGraph_t *graph, hipGraphExec_t *gexec)
@@ -1288,20 +944,6 @@ static int launch_range(bnr_exec &x, int count)
 {
     int done = 0;
     if (wants_qlist(x)) { int rq = build_qlist(x); if (rq) return rq; }
-#ifdef BNR_EXPERIMENTS
-    if (linear_mode(x) && x.graph_k > 0) {
-        // the lin streams start behind everything enqueued on x.stream so far and x.stream continues behind them
-        hipEvent_t e0 = nullptr;
-        HIPCHK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
-        HIPNOTE(hipEventRecord(e0, x.stream));
-        const int nls = x.lin_merge ? x.lin : 2 * x.lin;
-        for (int i = 0; i < nls; ++i) HIPNOTE(hipStreamWaitEvent(x.lstreams[i], e0, 0));
-        int rc = linear_range(x, count);
-        for (int i = 0; i < nls; ++i) { HIPNOTE(hipEventRecord(e0, x.lstreams[i])); HIPNOTE(hipStreamWaitEvent(x.stream, e0, 0)); }
-        (void)hipEventDestroy(e0);
-        return rc;
-    }
-#endif
     if (x.use_graph && !x.profiling && x.graph_k > 0) {     // profiling records HIP events around k_gram: eager launches
         int rc = exec_prepare(x);
         if (rc) return rc;
@@ -1512,9 +1154,6 @@ int bnr_group_create(bnr_chain *const *chains, int32_t nchains, bnr_group **out)
     g->m.assign(chains, chains + nchains);
     int rc = exec_init(g->x, chains[0]->device, nchains, &chains[0]->d);
     if (rc) { exec_free(g->x); delete g; return rc; }
-#ifdef BNR_EXPERIMENTS
-    g->x.gq = chains[0]->x.gq;
-#endif
     for (size_t i = 0; i < g->m.size(); ++i) g->x.cds_pin[i] = g->m[i]->d;   // host copy from the start: launch choices made at capture time (group_shares_x) read it
     for (bnr_chain *c : g->m) c->group = g;
     *out = g;
@@ -1598,24 +1237,7 @@ int bnr_group_run(bnr_group *g, int32_t first_index, int32_t nburn, int32_t tota
     return rc;
 }
 
-#ifdef BNR_EXPERIMENTS
-// the extra streams of the opt-in pipelined schedules are created when somebody asks for one (the default path creates nothing new)
-static int ensure_pipeline_streams(bnr_exec &x, int mode)
-{
-    HIPCHK(hipSetDevice(x.device));
-    if (!x.stream3) {
-        // the factorization branch on a HIGH-priority queue (it did not help against a many-round Gram that has workgroups waiting for a
-        // slot -- the dispatcher does not get round to other queues until the grid is dispatched -- but it does no harm either)
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
-        HIPCHK(hipStreamCreateWithPriority(&x.stream3, hipStreamNonBlocking, hi));
-    }
-    if (!x.stream4) HIPCHK(hipStreamCreateWithFlags(&x.stream4, hipStreamNonBlocking));
-    (void)mode;                                                            // (the resident Gram k_gram8q keeps off cu ids by mask: no census of compute units)
-    return BNR_OK;
-}
-#endif
-// Options that exist only in a library built with -DBNR_EXPERIMENTS (csrc/bnr_experiments.h): the shipped library refuses them by name, so that
+// Options of the measured experiments of rounds 3-4 (kernels and host paths removed from the tree in round 5: tools/experiments/README.md): refused by name, so that
 // nothing a user can set starts a kernel that polls device memory
 static bool experimental_option(const char *name)
 {
@@ -1627,17 +1249,10 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
 {
     if (!strcmp(name, "graph")) { x.use_graph = (int)value; return BNR_OK; }
     if (!strcmp(name, "overlap")) { x.overlap = (int)value; drop_graph(x); return BNR_OK; }
-#ifndef BNR_EXPERIMENTS
-    if (experimental_option(name)) return fail(BNR_ERR_BAD_ARG, std::string("option ") + name + " belongs to the measured experiments: build the library with -DBNR_EXPERIMENTS (tools/r4_build_variants.sh)");
-#endif
+    if (experimental_option(name)) return fail(BNR_ERR_BAD_ARG, std::string("option ") + name + " belongs to the measured experiments of rounds 3-4, which are no longer part of the library (tools/experiments/README.md)");
     if (!strcmp(name, "gram_variant")) {
-#ifdef BNR_EXPERIMENTS
-        const bool ok = value == 0 || value == 8 || value == 16 || (value >= 9 && value <= 14);
-        const char *msg = "gram_variant must be 0 (auto), 8, 16, or an experiment: 9 (persistent, two per CU), 10 (LDS-DMA), 11 / 12 / 14 (one resident round, static task loop), 13 (resident, per-CU work lists, reserved CUs)";
-#else
         const bool ok = value == 0 || value == 8 || value == 16;
-        const char *msg = "gram_variant must be 0 (auto), 8 or 16 (the experimental kernels 9..14 need a library built with -DBNR_EXPERIMENTS)";
-#endif
+        const char *msg = "gram_variant must be 0 (auto), 8 or 16 (the experimental kernels 9..14 of rounds 3-4 are no longer part of the library: tools/experiments/README.md)";
         if (!ok) return fail(BNR_ERR_BAD_ARG, msg);
         x.gram_variant = (int)value; drop_graph(x); return BNR_OK;
     }
@@ -1658,60 +1273,12 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
         x.spw_cap = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "factor_variant")) {
-#ifdef BNR_EXPERIMENTS
-        const bool ok = value >= -1 && value <= 5;
-#else
         const bool ok = value >= -1 && value <= 3 && value != 1;
-#endif
-        if (!ok) return fail(BNR_ERR_BAD_ARG, "factor_variant must be -1 (auto), 0 (right-looking), 2 (right-looking, two panels per launch) or 3 (2 with the K = 128 trailing update); 1 (left-looking), 4 (data-flow, one launch) and 5 (one workgroup per chain, n_pad <= 128) are experiments (-DBNR_EXPERIMENTS)");
+        if (!ok) return fail(BNR_ERR_BAD_ARG, "factor_variant must be -1 (auto), 0 (right-looking), 2 (right-looking, two panels per launch) or 3 (2 with the K = 128 trailing update); 1 (left-looking), 4 (data-flow, one launch) and 5 (one workgroup per chain, n_pad <= 128) were experiments of rounds 3-4, no longer part of the library (tools/experiments/README.md)");
         x.factor_variant = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "graph_k")) { if (value < 1 || value > 256) return fail(BNR_ERR_BAD_ARG, "graph_k out of range"); x.graph_k = (int)value; drop_graph(x); return BNR_OK; }
     if (!strcmp(name, "profiling")) { if (x.profiling != (int)value) drop_graph(x); x.profiling = (int)value; return BNR_OK; }
-#ifdef BNR_EXPERIMENTS
-    if (!strcmp(name, "nop_fork")) {
-        if (value < 0 || value > 1) return fail(BNR_ERR_BAD_ARG, "nop_fork must be 0 or 1");
-        if (value == 1 && !x.stream4) { HIPCHK(hipSetDevice(x.device)); HIPCHK(hipStreamCreateWithFlags(&x.stream4, hipStreamNonBlocking)); }
-        x.nop_fork = (int)value; drop_graph(x); return BNR_OK;
-    }
-    if (!strcmp(name, "resv_mask")) {
-        if (value < 0 || (value & ~0xfe) || __builtin_popcountll((unsigned long long)value) > 4) return fail(BNR_ERR_BAD_ARG, "resv_mask: bits 1..7 = cu ids inside a shader engine that the resident Gram leaves free, four at most");
-        x.resv_mask = (int)value; drop_graph(x); return BNR_OK;
-    }
-    if (!strcmp(name, "crit_origin")) {
-        if (value < 0 || value > 2) return fail(BNR_ERR_BAD_ARG, "crit_origin must be 0, 1 or 2");
-        if (value == 2 && !x.stream4) { HIPCHK(hipSetDevice(x.device)); HIPCHK(hipStreamCreateWithFlags(&x.stream4, hipStreamNonBlocking)); }
-        x.crit_origin = (int)value; drop_graph(x); return BNR_OK;
-    }
-    if (!strcmp(name, "group_backproj")) {
-        if (value < 0 || value > 1) return fail(BNR_ERR_BAD_ARG, "group_backproj must be 0 (default) or 1");
-        x.group_backproj = (int)value; drop_graph(x); return BNR_OK;
-    }
-    if (!strcmp(name, "linear_debug")) { x.lin_debug = (int)value; drop_graph(x); return BNR_OK; }
-    if (!strcmp(name, "linear") || !strcmp(name, "linear_merge")) {
-        // the two options size the same stream array: whichever is set last, every stream capture_linear / linear_range index exists
-        const int lin = !strcmp(name, "linear") ? (int)value : x.lin, merge = !strcmp(name, "linear_merge") ? (value ? 1 : 0) : x.lin_merge;
-        if (lin != 0 && lin != 1 && lin != 2 && lin != 4) return fail(BNR_ERR_BAD_ARG, "linear must be 0 (off), 1, 2 or 4 (parts)");
-        if (lin == 4 && !merge) return fail(BNR_ERR_BAD_ARG, "linear = 4 needs linear_merge = 1 (set it first): eight streams on four hardware queues end in gate timeouts (profiles/round3_experiments_notes.txt I)");
-        HIPCHK(hipSetDevice(x.device));
-        HIPCHK(hipStreamSynchronize(x.stream));
-        drop_graph(x);
-        while ((int)x.lstreams.size() < (merge ? 1 : 2) * lin) {
-            hipStream_t st = nullptr;
-            HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            x.lstreams.push_back(st);
-        }
-        if (lin && !x.lflags) { HIPCHK(hipMalloc((void **)&x.lflags, sizeof(unsigned long long) * 64)); HIPCHK(hipMemsetAsync(x.lflags, 0, sizeof(unsigned long long) * 64, x.stream)); }
-        x.lin = lin; x.lin_merge = merge;
-        return BNR_OK;
-    }
-    if (!strcmp(name, "pipeline")) {
-        if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "pipeline must be -1 (auto), 0 or 1");
-        if (value > 0) { int rc = ensure_pipeline_streams(x, (int)value); if (rc) return rc; }
-        x.pipeline = (int)value; drop_graph(x); return BNR_OK;
-    }
-    if (!strcmp(name, "gate_us")) { if (value < 0 || value > 1000000) return fail(BNR_ERR_BAD_ARG, "gate_us out of range"); x.gate_us = (int)value; drop_graph(x); return BNR_OK; }
-#endif
     return fail(BNR_ERR_BAD_ARG, std::string("unknown option ") + name);
 }
 static int exec_last_timing(bnr_exec &x, int which, double *avg_us, int64_t *launches)
@@ -2524,12 +2091,6 @@ static void launch_gram_only(bnr_chain *c)
         launch_gram_i8(c->x, 0, c->x.stream, ggrid);
         return;
     }
-#ifdef BNR_EXPERIMENTS
-    if (c->x.gram_variant == 11) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_one, 0>), dim3(3 * c->x.ncu), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1, c->x.gq);
-    else if (c->x.gram_variant == 12) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8s<bnr_one, 1>), dim3(3 * c->x.ncu), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1, c->x.gq);
-    else if (c->x.gram_variant == 9) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8p<bnr_one, false>), dim3(BNR_G8P_WPC * c->x.ncu), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1, c->x.gq, (const unsigned *)nullptr, c->x.gctl);
-    else
-#endif
     if (c->x.gram_variant == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram8<bnr_one>), dim3(round_up(ntl * d.ksplit, 8)), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1);
     else if (d.gram_kg == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 4>), dim3(round_up(ntl * d.ksplit, 8)), dim3(1024), 0, c->x.stream, bnr_one{d}, 0, 1);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram<bnr_one, 2>), dim3(round_up(ntl * d.ksplit, 8)), dim3(512), 0, c->x.stream, bnr_one{d}, 0, 1);
@@ -2558,19 +2119,11 @@ int bnr_chain_debug_time_gram(bnr_chain *c, int32_t reps, double *avg_us)
     return check_launch("debug_time_gram");
 }
 
-// timing experiments (library built with -DBNR_EXPERIMENTS only): flags read by the kernels of the scalar branch, see bnr_exp_flags
+// timing experiments of round 4 (skip the scalar branch / the late panel steps): no longer part of the library, the entry point refuses
 int bnr_debug_set_exp(int32_t device, int32_t flags)
 {
-#ifdef BNR_EXPERIMENTS
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipDeviceSynchronize());
-    int v = flags;
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(bnr_exp_flags), &v, sizeof v));
-    return BNR_OK;
-#else
     (void)device; (void)flags;
-    return fail(BNR_ERR_BAD_ARG, "this library was built without -DBNR_EXPERIMENTS");
-#endif
+    return fail(BNR_ERR_BAD_ARG, "the timing experiments of round 4 are no longer part of the library (tools/experiments/README.md)");
 }
 
 int bnr_chain_set_profiling(bnr_chain *c, int32_t enable)

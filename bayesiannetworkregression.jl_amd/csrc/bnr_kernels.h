@@ -22,8 +22,9 @@
 // of descriptors indexed by the grid's chain coordinate: bnr_many); the arithmetic of a chain is the same in both.
 // Outside the sweep: k_init_prior (initialize_variables!), k_fetch_cols / k_load_cols (Table layout), k_rhat_stats
 // (split-Rhat message), k_summary (Summary statistics).
-// Experiments (rounds 3-4: persistent / resident Gram kernels, left-looking and data-flow factorizations, gates, ...) live in
-// bnr_experiments.h, included at the end of this file only with -DBNR_EXPERIMENTS; the shipped library has none of them.
+//   k_x_mask, k_sdigits, k_gram_i8   the Gram of a binary (0/1) model matrix on the i8 matrix pipe (round 5)
+// The measured experiments of rounds 3-4 (persistent / resident Gram kernels, left-looking and data-flow factorizations, gates, ...) are not
+// part of this tree any more: tools/experiments/ keeps their kernels and drivers for the record (they built against the round-4 tree).
 #pragma once
 #include "bnr_rng.h"
 
@@ -113,18 +114,8 @@ struct bnr_many {
     __device__ __forceinline__ bnr_dev at(int c) const { return bnr_globalized(p + c); }
 };
 
-#ifdef BNR_EXPERIMENTS
-// timing experiments only (bnr_debug_set_exp): bit 0 = the kernels of the scalar branch return at once (k_node copies the scalar columns of
-// the previous row forward so that the critical chain keeps working on sane numbers) -- what the panel steps cost without company
-__device__ int bnr_exp_flags = 0;
-#define BNR_EXP_SKIP_SCALAR() (__builtin_amdgcn_readfirstlane(bnr_exp_flags) & 1)
-// bits 8..15 = N > 0: the panel steps p >= N of the factorization return at once (results are then wrong) -- how short would the sweep be if the
-// factorization were that much faster, i.e. where does the scalar branch take over as the critical chain?
-#define BNR_EXP_SKIP_CHOL(p) (((__builtin_amdgcn_readfirstlane(bnr_exp_flags) >> 8) & 255) != 0 && (p) >= ((__builtin_amdgcn_readfirstlane(bnr_exp_flags) >> 8) & 255))
-#else
 #define BNR_EXP_SKIP_SCALAR() 0
 #define BNR_EXP_SKIP_CHOL(p) 0
-#endif
 enum { ROW_TAU2 = 0, ROW_THETA = 1, ROW_DELTA = 2, ROW_MU = 3 };
 enum { SC_RR = 0, SC_SIGQ = 1, SC_TAU = 2, SC_TAU2N = 3, SC_TAU2N_IT = 4, SC_I8SCALE = 8 };   // TAU2N: tau2 pre-drawn by k_tail for iteration id TAU2N_IT
 
@@ -574,23 +565,11 @@ __device__ __forceinline__ double bnr_bufload_f64(__amdgpu_buffer_rsrc_t r, unsi
 }
 // A Gram workgroup has stored its partial tile: count it for the tile's column (the factorization checks the count before its
 // first read of the column).  k_gram / k_gram8 are consumed after the kernel boundary: one relaxed atomic, no fence.
-// Only the opt-in left-looking / pipelined factorization reads the counts (builds with -DBNR_EXPERIMENTS): the default library does not
+// Only the left-looking / pipelined factorization experiments of rounds 3-4 read the counts (tools/experiments/): the library does not
 // count at all (round 3 did, on every launch: one agent-scope atomic per workgroup on 8 words per chain).
-#ifdef BNR_EXPERIMENTS
-// One Gram launch = one epoch of the data-flow factorization that follows it (k_chol_df tags its hand-over flags with it: nothing has to be
-// zeroed between two sweeps, and a flag of an earlier factorization can never be mistaken for one of this).  Bumped by the workgroup of task slot 0.
-__device__ __forceinline__ void bnr_gram_epoch(const bnr_dev &cd, int gslot)
-{
-    if (gslot == 0 && threadIdx.x == 0) cd.dfctl[0] += 1u;
-}
-#endif
 __device__ __forceinline__ void bnr_gram_count(const bnr_dev &cd, int tj)
 {
-#ifdef BNR_EXPERIMENTS
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&cd.gprog[tj], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
     (void)cd; (void)tj;
-#endif
 }
 #define BNR_GRAM_KB 16                // columns of X per staged batch (4 MFMA k-steps): one barrier per 16 MFMAs of a wave
 #ifndef BNR_GRAM_SKIP_DEAD
@@ -782,9 +761,6 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
     int tj = t - ti * (ti + 1) / 2;
     bnr_gram16_task<KG, false>(bnr_geom_of(cd), Sp, cd.Gpart, t, ti, tj, ks, sred);
     bnr_gram_count(cd, tj);
-#ifdef BNR_EXPERIMENTS
-    bnr_gram_epoch(cd, gslot);
-#endif
 }
 
 // k_gram8: the same Gram, the same task map, the same summation order per element (bitwise the same partial tiles) -- for SIX
@@ -949,9 +925,6 @@ __global__ __launch_bounds__(512, 6) void k_gram8(const SRC chain_src, int s, in
     int tj = t - ti * (ti + 1) / 2;
     bnr_gram8_task<false>(bnr_geom_of(cd), Sp, cd.Gpart, t, ti, tj, ks, sred);
     bnr_gram_count(cd, tj);
-#ifdef BNR_EXPERIMENTS
-    bnr_gram_epoch(cd, gslot);
-#endif
 }
 
 // ===================================================================================== the Gram of a BINARY model matrix on the i8 matrix pipe
@@ -1917,14 +1890,6 @@ __global__ __launch_bounds__(256) void k_solve_w(const SRC chain_src)
     BNR_CRITICAL_PATH();
     const bnr_dev &cd = chain_src.get();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, np = cd.n_pad;
-#ifdef BNR_EXPERIMENTS
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // k_chol_df hands data over through ONE XCD's L2: its workgroups must all have run on the same XCD (they report it here)
-        const unsigned m = cd.dfctl[1];
-        if (m & (m - 1u)) atomicAdd((unsigned long long *)&cd.counters[8], 1ull);
-        cd.dfctl[1] = 0u;
-    }
-#endif
     const int c = blockIdx.x * 4 + wave;
     const size_t ld = bnr_ldE(np);
     const double *col = cd.E + (size_t)np + ld * (size_t)c;
@@ -2158,10 +2123,12 @@ __device__ inline void wave_tri_inverse(const double *A, double *T, int R, int l
     bnr_wsync();
 }
 
-#ifndef BNR_TAIL_THREADS
 #define BNR_TAIL_THREADS 512   // 8 wavefronts: the seven role waves of phase 3 + one; two per SIMD, so the kernel may use 256 vector registers (no spills: with
-                               // 1024 threads it had 128 and spilled) and fits a CU beside other resident workgroups instead of needing an empty one
-#endif
+                               // 1024 threads it had 128 and spilled) and fits a CU beside other resident workgroups instead of needing an empty one.
+                               // NOT a tunable: the block-wide reductions of k_tail (sum of squared residuals, sig_q, the mu / tau2 sums) stride by the thread
+                               // count, so another value changes their last bits (the tables then differ from this build's by rounding; round 3's 1024-thread
+                               // build differs from this one in exactly that way -- within 1e-9 of each other and of the CPU restatement the tests check against, not bit for bit)
+static_assert(BNR_TAIL_THREADS == 512, "k_tail's reductions depend on its thread count: see the note above");
 template <class SRC>
 __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, int s, int mask, int xg_src)
 {
@@ -2684,6 +2651,3 @@ __global__ __launch_bounds__(256) void k_acov(const double *buf, int nsamp, int 
     }
 }
 
-#ifdef BNR_EXPERIMENTS
-#include "bnr_experiments.h"
-#endif

@@ -233,8 +233,8 @@ int bnr_chain_debug_copy(bnr_chain *chain, int32_t which, double *out, int64_t c
  * bytes per mask row, digit planes), rowlen (doubles per trace row on the device)}; the Gram partials of debug_copy(3) are [ksplit][ntile (ntile + 1) / 2][64 x 64],
  * tile (ti >= tj) at index ti (ti + 1) / 2 + tj, element (i, j) of a tile at [j * 64 + i] */
 int bnr_chain_debug_dims(bnr_chain *chain, int32_t *out8);
-/* timing experiments: only a library built with -DBNR_EXPERIMENTS accepts it (the shipped one returns BNR_ERR_BAD_ARG).  flags bit 0: the
- * kernels of the scalar branch return at once (results are then NOT the sampler's) -- what the critical chain costs without company */
+/* timing experiments of round 4 (removed in round 5, tools/experiments/README.md): the entry point remains and returns BNR_ERR_BAD_ARG.  (flags bit 0 made the
+ * kernels of the scalar branch return at once -- what the critical chain costs without company.) */
 int bnr_debug_set_exp(int32_t device, int32_t flags);
 
 /* tunables (performance only; never change results):
@@ -243,12 +243,12 @@ int bnr_debug_set_exp(int32_t device, int32_t flags);
  *   "overlap"   1 (default): scalar branch and Gram/factorization branch of a sweep on two streams; 0: one stream
  *   "gram_variant" 0 (default): the Gram kernel is chosen per launch (k_gram8 when the launch has more than two workgroups per CU,
  *               k_gram otherwise); 8 / 16 force one of them.  Both write the same partial tiles bit for bit.  (9..14: the persistent /
- *               resident experiments of csrc/bnr_experiments.h, accepted only by a library built with -DBNR_EXPERIMENTS.)
+ *               resident experiments of rounds 3-4, removed from the tree in round 5 -- tools/experiments/README.md -- and refused by name.)
  *   "profiling" 1: record HIP events around every k_gram launch (forces eager launches), see bnr_chain_last_timing
  *   "factor_variant" -1 (default): chosen by size -- 0 below n_pad = 1024, 3 from there on; 0: right-looking factorization, one
  *               32-column panel per launch (k_gram_reduce + k_chol_step); 2: right-looking, two panels per launch (k_chol_step2); 3: 2 with
  *               the whole trailing matrix updated at every other launch only (K = 128); (1: left-looking k_chol_ll, 4: data-flow k_chol_df, 5: one workgroup per
- *               chain k_chol_small -- -DBNR_EXPERIMENTS only)
+ *               chain k_chol_small -- experiments of rounds 3-4, removed in round 5 and refused)
  *   "fuse_reduce" 1 / -1 (default): launch 0 of the one-panel factorization also sums the Gram's K-split partial tiles (no k_gram_reduce
  *               launch); 0: separate reduction pass
  *   "group_xpass" -1 (default): a lockstep group whose members share the device copy of X (bnr_chain_create_like) runs ONE X pass
@@ -257,8 +257,8 @@ int bnr_debug_set_exp(int32_t device, int32_t flags);
  *               their own in front of the scalar tail, off the critical chain; 1: always; 0: inside the back-projection
  *   "spw_cap"   1..4 (default 4): super blocks per update workgroup of the factorization, at most (diagnostics)
  *   Experiments ("nop_fork", "pipeline", "gate_us", "linear", "linear_merge", "linear_debug", "group_backproj", "resv_mask", "crit_origin"; rounds 3-4,
- *               profiles/round*_experiments_notes.txt): all measured no faster, part of them poll device memory.  They exist only in a library
- *               built with -DBNR_EXPERIMENTS (csrc/bnr_experiments.h, tools/r4_build_variants.sh); the shipped library refuses them by name.
+ *               profiles/round*_experiments_notes.txt): all measured no faster, part of them polled device memory.  Removed from the tree in
+ *               round 5 (tools/experiments/README.md): the library refuses them by name.
  *   "byte_x"    (chains only) 0: the X passes read the f64 matrix although a byte image of X exists; 1 (default): the byte image
  *               (kept when the model matrix came as Bool/UInt8, or as Int32/Int64 with every value in 0..255; docs/src/man/inputdata.md)
  *   "gram_i8"   (chains only; round 5) 1 (the default from n_pad^2 q >= 2.5e8 on, where it was measured faster -- n = 500, V = 100 and

@@ -31,6 +31,9 @@ end
 
 lasterr() = unsafe_string(ccall((:bnr_last_error, LIB), Cstring, ()))
 check(rc) = rc == 0 || error("libbnr_hip: $(lasterr()) (status $rc)")
+# run calls: status 4 (BNR_ERR_SAMPLER_CAP) = a rejection sampler stopped at its attempt cap in this call; the rows were written and the table stays valid
+# (the reference has no cap and never raises here): a fit must not die of one such draw -- warn and go on
+check_run(rc) = rc == 4 ? (@warn("libbnr_hip: a rejection sampler hit its attempt cap in this run call (rows written; see bnr_chain_counters)"); true) : check(rc)
 
 # element types the library converts on the device (enum of include/bnr_hip.h); anything else is promoted to Float64 here
 dtype_code(::Type{Float64}) = 0
@@ -115,10 +118,10 @@ function run!(x::Union{Group,Chain}, first_index, nburn, total, purge_burn; prog
     pb, pf = Int32(isnothing(purge_burn) ? 0 : purge_burn), Int32(tick === nothing ? 0 : prog_freq)
     # (the (name, library) target of a ccall must be a constant expression: two literal calls, not a symbol chosen at run time)
     if x isa Group
-        check(ccall((:bnr_group_run, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}),
+        check_run(ccall((:bnr_group_run, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}),
             x.h, first_index, nburn, total, pb, pf, cb, C_NULL, nxt))
     else
-        check(ccall((:bnr_chain_run, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}),
+        check_run(ccall((:bnr_chain_run, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}),
             x.h, first_index, nburn, total, pb, pf, cb, C_NULL, nxt))
     end
     Int(nxt[])
@@ -199,6 +202,8 @@ function generate_samples!(X, y, R; Î·=1.01, Î¶=1.0, Î¹=1.0, aÎ”=1.0, bÎ”=1.0, Î
         purge_burn = nothing
     end
     tot_save = isnothing(purge_burn) ? total : nsamp + purge_burn
+    # several ranks (comm given): every rank must run the SAME seed, or chain c on one rank is not the chain c the others assume -- refuse to draw one per rank
+    isnothing(seed) && !isnothing(comm) && error("BNRHip: with a communicator the caller must pass ONE seed to every rank (draw it on rank 0 and broadcast it, gibbs.jl:739, 928)")
     seed = isnothing(seed) ? rand(1:55555) : seed
     rank, world = comm === nothing ? (0, 1) : (comm.rank, comm.world)
     ids = [c for c in 1:num_chains if (c - 1) % world == rank]                   # pmap's round-robin over workers
@@ -256,6 +261,8 @@ function generate_samples_dbl!(X, y, R; Î·=1.01, Î¶=1.0, Î¹=1.0, aÎ”=1.0, bÎ”=1.
         purge_burn = nothing
     end
     tot_save = isnothing(purge_burn) ? total : nsamp + purge_burn
+    # several ranks (comm given): every rank must run the SAME seed, or chain c on one rank is not the chain c the others assume -- refuse to draw one per rank
+    isnothing(seed) && !isnothing(comm) && error("BNRHip: with a communicator the caller must pass ONE seed to every rank (draw it on rank 0 and broadcast it, gibbs.jl:739, 928)")
     seed = isnothing(seed) ? rand(1:55555) : seed
     rank, world = comm === nothing ? (0, 1) : (comm.rank, comm.world)
     ids = [c for c in 1:num_chains if (c - 1) % world == rank]
@@ -302,6 +309,8 @@ end
 function Fit!(X, y, R; Î·=1.01, V=30, Î¶=1.0, Î¹=1.0, aÎ”=1.0, bÎ”=1.0, Î½=10, nburn=30000, nsamples=20000, mingen=0, maxgen=0,
               psrf_cutoff=1.01, x_transform=true, suppress_timer=false, num_chains=2, seed=nothing, purge_burn=nothing,
               filename="parameters.log", device=0, comm::Union{Comm,Nothing}=nothing, tick=nothing)
+    # several ranks (comm given): every rank must run the SAME seed, or chain c on one rank is not the chain c the others assume -- refuse to draw one per rank
+    isnothing(seed) && !isnothing(comm) && error("BNRHip: with a communicator the caller must pass ONE seed to every rank (draw it on rank 0 and broadcast it, gibbs.jl:739, 928)")
     seed = isnothing(seed) ? rand(1:55555) : seed                # (with several ranks the caller passes ONE seed to all of them, see generate_samples!)
     if comm === nothing || comm.rank == 0
         open(filename, "w") do logfile

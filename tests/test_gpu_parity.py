@@ -1272,9 +1272,10 @@ def test_post_burn_in_rows_match_the_oracle_at_config3(gpu):
 
 def test_experimental_options_are_refused_by_the_shipped_library(gpu, test1):
     """The measured experiments of rounds 3 and 4 (left-looking factorization behind progress gates, persistent / resident Gram kernels with task
-    queues and reserved CUs, the pipelined and "linear" schedules, the group back-projection: csrc/bnr_experiments.h) are compiled only with
-    -DBNR_EXPERIMENTS; part of them poll device memory.  The library a user loads has none of them: every option that would select one is
-    refused by name, for a chain and for a group, and the chain works on as before."""
+    queues and reserved CUs, the pipelined and "linear" schedules, the group back-projection) were removed from the tree in round 5
+    (tools/experiments/ keeps their kernels and drivers for the record); part of them polled device memory.  The library has none of them:
+    every option that would select one is refused by name with a pointer to that directory, for a chain and for a group, and the chain works
+    on as before."""
     X, y = test1
     ch = bnr_amd.Chain(X, y, 5, 8, 3, 1)
     mate = bnr_amd.Chain.like(ch, 3, 2, 8)
@@ -1282,7 +1283,7 @@ def test_experimental_options_are_refused_by_the_shipped_library(gpu, test1):
     for target in (ch, g):
         for name, value in (("pipeline", 1), ("linear", 2), ("linear_merge", 1), ("gate_us", 100), ("group_backproj", 1), ("resv_mask", 0x80),
                             ("crit_origin", 1), ("gram_variant", 9), ("gram_variant", 10), ("gram_variant", 13), ("factor_variant", 1), ("factor_variant", 4), ("factor_variant", 5), ("nop_fork", 1)):
-            with pytest.raises(bnr_amd.BnrError, match="BNR_EXPERIMENTS"):
+            with pytest.raises(bnr_amd.BnrError, match="tools/experiments"):
                 target.set_option(name, value)
     assert bnr_amd.lib().bnr_debug_set_exp(0, 1) != 0
     for c in (ch, mate):
@@ -1329,7 +1330,7 @@ def test_factorization_variants_are_bitwise_equal(gpu):
     launch, which sums the Gram's K-split partial tiles itself (fuse_reduce), against the separate k_gram_reduce pass, and the group's X pass
     with one workgroup per column chunk for all members (group_xpass) against the per-chain kernel, and the partial sums as a launch of their
     own (split_sums).  (The experimental variants -- left-looking factorization, resident Gram kernels, pipelined schedule, group
-    back-projection -- are checked the same way by tools/ab_factor.py against a -DBNR_EXPERIMENTS build, outside this suite.)"""
+    back-projection -- were checked the same way by tools/experiments/ab_factor.py against the round-4 experiments build.)"""
     for (n, V, R) in [(70, 19, 5), (193, 30, 5), (64, 9, 2), (500, 40, 4), (1000, 12, 3)]:
         X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=7)
         tabs = {}

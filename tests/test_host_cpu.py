@@ -366,3 +366,30 @@ def test_fit_in_a_fresh_process_does_not_pull_in_torch():
     assert "NOTORCH" in out, out
     assert "another HIP runtime" not in out, out            # (without a GPU the call ends in BNR_ERR_HIP from hipGetDeviceCount: no CPU fallback)
     assert out.startswith("RAN") or "no ROCm-capable device" in out or "HIP" in out, out
+
+
+def test_a_capped_draw_does_not_abort_a_fit():
+    """the C ABI reports BNR_ERR_SAMPLER_CAP (status 4) by the call it happened in, but the rows are written and the table stays valid
+    (the reference's rejection loops are unbounded and never raise).  The fit drivers (generate_samples, generate_samples_dbl, Fit -- all through
+    ChainSet.run) therefore warn and go on instead of dying of one capped draw in tens of thousands of iterations; any other status still raises.
+    Host logic only: the chains are stand-ins that raise what the library would."""
+    from bnr_amd import api, _capi
+
+    class Fake:
+        def __init__(self, code): self.code, self.calls = code, 0
+        def run(self, *a):
+            self.calls += 1
+            if self.code: raise _capi.BnrError(self.code, "libbnr_hip: stand-in")
+
+    for group in (False, True):
+        cs = api.ChainSet.__new__(api.ChainSet)
+        capped, fine = Fake(_capi.BNR_ERR_SAMPLER_CAP), Fake(0)
+        cs.ids, cs.chains, cs.group = [1, 2], {1: capped, 2: fine}, (capped if group else None)
+        with pytest.warns(RuntimeWarning, match="attempt cap"):
+            cs.run(2, 10, 10, 0)
+        assert capped.calls == 1 and (group or fine.calls == 1)            # the other chains of the rank still run
+        broken = Fake(_capi.BNR_ERR_CHOLESKY)
+        cs.chains, cs.group = {1: broken, 2: fine}, (broken if group else None)
+        with pytest.raises(_capi.BnrError):
+            cs.run(2, 10, 10, 0)
+
