@@ -49,7 +49,7 @@ __global__ __launch_bounds__(1024) void k_sdigits(const args_t A)
     }
 }
 
-template <int L>
+template <int L, int EXP = 0>
 __global__ __launch_bounds__(256, 2) void k_gram_i8(const args_t A)
 {
     const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
@@ -80,23 +80,27 @@ __global__ __launch_bounds__(256, 2) void k_gram_i8(const args_t A)
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[l][a][b] = i4{0, 0, 0, 0};
     const int nstep = A.kcp / 64;
+    // operands two k-steps ahead (an L2 round trip is longer than one k-step's MFMAs)
     i4 a0 = *(const i4 *)pa0, a1 = *(const i4 *)(pa0 + r16), b0 = *(const i4 *)pb0, b1 = *(const i4 *)(pb0 + r16);
+    i4 pa_0 = a0, pa_1 = a1, pb_0 = b0, pb_1 = b1;
+    if (nstep > 1) { pa_0 = *(const i4 *)(pa0 + 64); pa_1 = *(const i4 *)(pa0 + r16 + 64); pb_0 = *(const i4 *)(pb0 + 64); pb_1 = *(const i4 *)(pb0 + r16 + 64); }
     for (int st = 0; st < nstep; ++st) {
-        i4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
-        if (st + 1 < nstep) {
-            const int o = 64 * (st + 1);
+        i4 na0 = pa_0, na1 = pa_1, nb0 = pb_0, nb1 = pb_1;
+        if (st + 2 < nstep && !(EXP & 1)) {
+            const int o = 64 * (st + 2);
             na0 = *(const i4 *)(pa0 + o); na1 = *(const i4 *)(pa0 + r16 + o); nb0 = *(const i4 *)(pb0 + o); nb1 = *(const i4 *)(pb0 + r16 + o);
         }
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            const i4 d = sD[l * ng + st * 4 + lq];
-            const i4 m0 = b0 & d, m1 = b1 & d;
+            const i4 d = (EXP & 4) ? b0 : sD[l * ng + st * 4 + lq];
+            const i4 m0 = (EXP & 2) ? ((l & 1) ? b0 : b1) : (b0 & d), m1 = (EXP & 2) ? ((l & 1) ? b1 : b0) : (b1 & d);
             acc[l][0][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, m0, acc[l][0][0], 0, 0, 0);
             acc[l][0][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, m1, acc[l][0][1], 0, 0, 0);
             acc[l][1][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, m0, acc[l][1][0], 0, 0, 0);
             acc[l][1][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, m1, acc[l][1][1], 0, 0, 0);
         }
-        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        a0 = pa_0; a1 = pa_1; b0 = pb_0; b1 = pb_1;
+        pa_0 = na0; pa_1 = na1; pb_0 = nb0; pb_1 = nb1;
     }
     // acc[l][jt][it][r]: j = wj*32 + jt*16 + 4 lq + r, i = wi*32 + it*16 + ln; T_l = - acc (A held -x)
     const double sc = -A.scale[chain][0];
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void k_gram_i8(const args_t A)
             }
 }
 
-template <int L>
+template <int L, int EXP = 0>
 static void run(int n, int V, int nchains, int ksplit, double srange)
 {
     const int q = V * (V + 1) / 2, n_pad = (n + 63) / 64 * 64, ntile = n_pad / 64, ntl = ntile * (ntile + 1) / 2;
@@ -138,13 +142,13 @@ static void run(int n, int V, int nchains, int ksplit, double srange)
     }
     const int grid = (ntl * ksplit + 7) / 8 * 8 * nchains;
     hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
-    for (int i = 0; i < 3; ++i) { k_sdigits<L><<<nchains, 1024>>>(A); k_gram_i8<L><<<grid, 256, (size_t)L * kcp>>>(A); }
+    for (int i = 0; i < 3; ++i) { k_sdigits<L><<<nchains, 1024>>>(A); k_gram_i8<L, EXP><<<grid, 256, (size_t)L * kcp>>>(A); }
     CK(hipDeviceSynchronize());
     const int reps = 30;
     CK(hipEventRecord(e0));
     for (int i = 0; i < reps; ++i) k_sdigits<L><<<nchains, 1024>>>(A);
     CK(hipEventRecord(e1));
-    for (int i = 0; i < reps; ++i) k_gram_i8<L><<<grid, 256, (size_t)L * kcp>>>(A);
+    for (int i = 0; i < reps; ++i) k_gram_i8<L, EXP><<<grid, 256, (size_t)L * kcp>>>(A);
     CK(hipEventRecord(e2)); CK(hipDeviceSynchronize());
     float ms0, ms1; CK(hipEventElapsedTime(&ms0, e0, e1)); CK(hipEventElapsedTime(&ms1, e1, e2));
     // check against the plain f64 sum on sampled entries, relative to max |G|
@@ -169,8 +173,8 @@ static void run(int n, int V, int nchains, int ksplit, double srange)
         for (double e : errs) worst = std::max(worst, e / gmax);
         (void)smax;
     }
-    printf("n=%d V=%d q=%d  %d chains  L=%d slices  ksplit %d (kchunk %d, padded %d)  S range e^+-%.0f:  digits %.2f us  Gram %.2f us per launch   worst |err| / max|G| = %.2e (bound q 2^(1-7L) = %.2e)\n",
-           n, V, q, nchains, L, ksplit, kchunk, kcp, srange, ms0 * 1e3 / reps, ms1 * 1e3 / reps, worst, q * ldexp(1.0, 1 - 7 * L));
+    printf("EXP=%d n=%d V=%d q=%d  %d chains  L=%d slices  ksplit %d (kchunk %d, padded %d)  S range e^+-%.0f:  digits %.2f us  Gram %.2f us per launch   worst |err| / max|G| = %.2e (bound q 2^(1-7L) = %.2e)\n",
+           EXP, n, V, q, nchains, L, ksplit, kchunk, kcp, srange, ms0 * 1e3 / reps, ms1 * 1e3 / reps, worst, q * ldexp(1.0, 1 - 7 * L));
     fflush(stdout);
     CK(hipFree(dXM));
     for (int c = 0; c < nchains; ++c) { CK(hipFree(dS[c])); CK(hipFree(dG[c])); CK(hipFree(dsc[c])); CK(hipFree(dD[c])); }
@@ -178,6 +182,11 @@ static void run(int n, int V, int nchains, int ksplit, double srange)
 
 int main()
 {
+    if (getenv("LAB_ABLATE")) {
+        run<8, 0>(500, 100, 8, 7, 3.0); run<8, 1>(500, 100, 8, 7, 3.0); run<8, 2>(500, 100, 8, 7, 3.0); run<8, 4>(500, 100, 8, 7, 3.0); run<8, 7>(500, 100, 8, 7, 3.0);
+        run<9, 0>(500, 300, 8, 48, 3.0); run<9, 1>(500, 300, 8, 48, 3.0); run<9, 2>(500, 300, 8, 48, 3.0); run<9, 7>(500, 300, 8, 48, 3.0);
+        return 0;
+    }
     for (int ks : {1, 2, 3, 4, 7}) run<8>(500, 100, 8, ks, 3.0);
     for (int ks : {1, 2, 3, 7}) run<8>(500, 100, 1, ks, 3.0);
     for (int ks : {4, 8, 16, 48}) run<9>(500, 300, 8, ks, 3.0);
