@@ -318,7 +318,7 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     // the i8 Gram of a binary model matrix (k_gram_i8): K slices padded to whole 64-column MFMA steps, digit planes of S for 1e-12 of max |G|
     d.kcp = round_up(kchunk, 64);
     d.kslab = d.kcp * d.ksplit;
-    d.i8L = std::min(9, std::max(7, (int)std::ceil((std::log2((double)std::max(d.q, 2)) + 41.0) / 7.0)));
+    d.i8L = (8.0 * d.q * std::ldexp(1.0, -56) <= 1e-12) ? 7 : 8;            // digit planes: 8 q 2^(-8 L) <= 1e-12 (7 up to q = 9007)
     // row layout
     int o = 4;
     d.o_xi = o; o += V;
@@ -725,7 +725,7 @@ static bool gram_on_i8(const bnr_exec &x)
 }
 #define BNR_LAUNCH_I8(LL)                                                                                                                   \
     do {                                                                                                                                    \
-        const size_t lds = (size_t)(LL) * d.kcp;                                                                                            \
+        const size_t lds = bnr_i8_lds_bytes(LL, d.kcp);                                                                                     \
         if (x.nb == 1) {                                                                                                                    \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sdigits<bnr_one, LL>), dim3(1), dim3(1024), 0, st, bnr_one{d}, s);                          \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram_i8<bnr_one, LL>), ggrid, dim3(256), lds, st, bnr_one{d}, s, 1);                        \
@@ -738,8 +738,7 @@ static void launch_gram_i8(bnr_exec &x, int s, hipStream_t st, dim3 ggrid)
 {
     const bnr_dev &d = *x.shape;
     if (d.i8L == 7) BNR_LAUNCH_I8(7);
-    else if (d.i8L == 8) BNR_LAUNCH_I8(8);
-    else BNR_LAUNCH_I8(9);
+    else BNR_LAUNCH_I8(8);
 }
 static void launch_gram(bnr_exec &x, int s, hipStream_t st, bool timed)
 {

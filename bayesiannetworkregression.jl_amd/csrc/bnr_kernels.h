@@ -50,8 +50,8 @@ struct bnr_dev {
     // binary model matrix (every entry 0 or 1: the reference's adjacency data, docs/src/man/inputdata.md:5-10): the Gram on the i8 matrix pipe
     const unsigned char *XM;     // [n_pad][kslab] row-major byte MASK of X (0xFF where X = 1): column k = ks kchunk + kk at byte ks kcp + kk of a row
                                  // (every K slice padded with zeros to a multiple of 64 columns = one v_mfma_i32_16x16x64_i8 step); nullptr: no such image
-    unsigned char *Sdig;         // [i8L][kslab] the 7-bit digits of the chain's S in the same column order (k_sdigits), its scale in scal[SC_I8SCALE]
-    int kcp, kslab, i8L;         // padded K slice, bytes per row of XM, number of digit planes (7..9)
+    unsigned char *Sdig;         // [i8L][kslab] the balanced base-256 digits of the chain's S in the same column order (k_sdigits), its scale in scal[SC_I8SCALE]
+    int kcp, kslab, i8L;         // padded K slice, bytes per row of XM, number of digit planes (7 or 8)
     // state
     double *trace;
     const bnr_plan_entry *plan;
@@ -930,14 +930,18 @@ __global__ __launch_bounds__(512, 6) void k_gram8(const SRC chain_src, int s, in
 // ===================================================================================== the Gram of a BINARY model matrix on the i8 matrix pipe
 // (reference: docs/src/man/inputdata.md:5-10 -- the inputs are 0/1 adjacency data --, X_new = Matrix{eltype(T)} gibbs.jl:917, the
 // product Xtau tau2 D Xtau' of gibbs.jl:434.)  With x in {0, 1}:  G[i][j] = sum_k x_ik x_jk S_k.
-//   k_sdigits   S_k = sum_{l < L} d_l[k] 2^(e - 7 (l + 1)) + r_k,  d_l in 0..127,  2^e > max S,  0 <= r_k < 2^(e - 7 L)   (a 7 L-bit fixed point image
-//               of S under the exponent of its largest entry: entries far below the largest lose relative precision, G does not -- see the bound)
+//   k_sdigits   S_k = sum_{l < L} d_l[k] 256^(L - 1 - l) 2^(e - 8 L + 2) + r_k,  d_l in -128..127 (balanced base-256 digits),  2^e > max S,
+//               0 <= r_k < 2^(e - 8 L + 2)   (an (8 L - 2)-bit fixed point image of S under the exponent of its largest entry: entries far below the largest lose
+//               relative precision, G does not -- see the bound)
 //   k_gram_i8   T_l = X diag(d_l) X' EXACTLY in i32 (v_mfma_i32_16x16x64_i8; A = the byte mask of the j rows = -x, B = mask AND digits = x d of the
-//               i rows; |T_l| <= 127 kchunk), then G = - sum_l T_l 2^(e - 7 (l + 1)) by Horner in f64 (L roundings of relative size 2^-53).
-// Error against the exact Gram: 0 <= G_exact - G <= q 2^(e - 7 L) <= 2 q 2^(-7 L) max_k S_k, and max |G| >= max_k S_k as soon as the column of the largest S
-// has a one: relative to max |G| at most 2 q 2^(-7 L) -- L = ceil((log2 q + 41) / 7) (8 at q = 5050, 9 at q = 45150) keeps that below 1e-12, the size of the f64
-// path's own rounding.  Same tasks, K slices and partial-tile layout as k_gram8: the reduction in launch 0 of the factorization does not know the difference.
-// Measured (tools/gram_i8_lab.hip, profiles/round5_gram_i8.txt): 8 chains at n = 500, V = 100: 62 us per launch + 6 us for the digits against 192 us.
+//               i rows; |T_l| <= 128 kchunk), then G = - sum_l T_l 256^(L - 1 - l) 2^(e - 8 L + 2) by Horner in f64 (L roundings of relative size 2^-53).
+// Error against the exact Gram: 0 <= G_exact - G <= q 2^(e - 8 L + 2) <= 8 q 2^(-8 L) max_k S_k, and max |G| >= max_k S_k as soon as the column of the largest S
+// has a one: relative to max |G| at most 8 q 2^(-8 L) -- L = 7 up to q = 9007 (5.6e-13 at q = 5050), L = 8 beyond (2e-14 at q = 45150): below 1e-12, the size of
+// the f64 path's own rounding.  Same tasks, K slices and partial-tile layout as k_gram8: the reduction in launch 0 of the factorization does not know the difference.
+// The loop (tools/gram_i8_lab.hip, profiles/round5_gram_i8.txt): X tiles staged through LDS in full 128-byte lines (direct 16-byte fragment loads were bound by
+// the CU's vector-memory path: every tile row fetched by two waves, half a line at a time), a wave = 16 i rows x all 64 j rows (ONE masked B fragment per plane for
+// four MFMAs); what bounds it now is LDS bandwidth (per k-step and wave five 1 KiB fragment reads + L digit reads for 4 L MFMAs of 16 cycles).
+// Measured: 8 chains at n = 500, V = 100: 50 us per launch + 6 us for the digits against 190 us on the f64 pipe.
 __global__ void k_x_mask(const unsigned char *X8, int n, int n_pad, int q, int kchunk, int kcp, int kslab, unsigned char *XM, int *not_binary)
 {
     // one thread per (row, 16-byte group) of XM; X8 is column-major (leading dimension n_pad): a one-off transpose at chain creation
@@ -976,19 +980,28 @@ __global__ __launch_bounds__(1024) void k_sdigits(const SRC chain_src, int s)
     for (int w = 1; w < 16; ++w) m = fmax(m, red[w]);
     int e;
     (void)frexp(m, &e);                                       // m = f 2^e with f in [0.5, 1): every S_k < 2^e
-    const double up = ldexp(1.0, 7 * L - e);                  // S_k up < 2^(7 L) <= 2^63
-    if (tid == 0) cd.scal[SC_I8SCALE] = ldexp(1.0, e - 7 * L);
+    constexpr int BITS = 8 * L - 2;                           // S_k up < 2^BITS <= 2^62: the top digit stays below 64, a carry cannot overflow it
+    const double up = ldexp(1.0, BITS - e);
+    if (tid == 0) cd.scal[SC_I8SCALE] = ldexp(1.0, e - BITS);
     const int kchunk = cd.q_pad / cd.ksplit;
     for (int idx = tid; idx < cd.kslab; idx += 1024) {
         const int ks = idx / cd.kcp, kk = idx % cd.kcp, k = ks * kchunk + kk;
         unsigned long long N = 0;
         if (kk < kchunk && k < cd.q) N = (unsigned long long)(S[k] * up);
+        // balanced base-256 digits, least significant first: a byte >= 128 stands for byte - 256 and carries one into the next
+        unsigned carry = 0;
 #pragma unroll
-        for (int l = 0; l < L; ++l) cd.Sdig[(size_t)l * cd.kslab + idx] = (unsigned char)((N >> (7 * (L - 1 - l))) & 127ull);
+        for (int l = L - 1; l >= 0; --l) {
+            const unsigned b = (unsigned)((N >> (8 * (L - 1 - l))) & 255ull) + carry;
+            carry = b >= 128u ? 1u : 0u;
+            cd.Sdig[(size_t)l * cd.kslab + idx] = (unsigned char)(b & 255u);
+        }
     }
 }
-// one (tile, K slice) task per 256-thread workgroup: 2 x 2 waves of 32 x 32, each 2 x 2 MFMA blocks x L digit planes (16 L accumulator registers);
-// operands straight from L2 in fragment layout (16 consecutive bytes of a row per lane), the slice's digits in LDS (L x kcp bytes, dynamic)
+// one (tile, K slice) task per 256-thread workgroup; dynamic LDS = 2 buffers x [I tile | J tile] x 64 rows x 144 bytes + L x kcp bytes of digits
+#define BNR_I8_RS 144                                         // bytes per staged row: 128 (two k-steps) + 16 of padding -- conflict-free ds_read_b128 fragments
+#define BNR_I8_TB (64 * BNR_I8_RS)
+__host__ __device__ inline size_t bnr_i8_lds_bytes(int L, int kcp) { return (size_t)4 * BNR_I8_TB + (size_t)L * kcp; }
 template <class SRC, int L>
 __global__ __launch_bounds__(256, 2) void k_gram_i8(const SRC chain_src, int s, int nchains)
 {
@@ -1002,58 +1015,72 @@ __global__ __launch_bounds__(256, 2) void k_gram_i8(const SRC chain_src, int s, 
     const int ks = task >> 16;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     const int tj = t - ti * (ti + 1) / 2;
-    extern __shared__ bnr_i4 sDig[];                          // [l][kcp / 16]
+    extern __shared__ bnr_i4 smem_i8[];
+    unsigned char *sX = (unsigned char *)smem_i8;             // [buf][I | J][64 rows][144]
+    bnr_i4 *sDig = (bnr_i4 *)(sX + 4 * BNR_I8_TB);            // [l][kcp / 16]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ln = lane & 15, lq = lane >> 4;
-    const int wi = (wave >> 1) & 1, wj = wave & 1;
     const int ng = cd.kcp / 16;
     for (int idx = tid; idx < L * ng; idx += 256) {
         const int l = idx / ng, g = idx % ng;
         sDig[idx] = *(const bnr_i4 *)(cd.Sdig + (size_t)l * cd.kslab + (size_t)ks * cd.kcp + 16 * g);
     }
-    __syncthreads();
-    const unsigned char *pa0 = cd.XM + (size_t)(tj * BNR_GT + wj * 32 + ln) * cd.kslab + (size_t)ks * cd.kcp + 16 * lq;     // j rows: A operand, the raw mask (= -x)
-    const unsigned char *pb0 = cd.XM + (size_t)(ti * BNR_GT + wi * 32 + ln) * cd.kslab + (size_t)ks * cd.kcp + 16 * lq;     // i rows: B operand, mask AND digit (= x d)
-    const size_t r16 = (size_t)16 * cd.kslab;
-    bnr_i4 acc[L][2][2];
+    // staging: thread -> rows tid / 8 and tid / 8 + 32 of both tiles, 16-byte column tid % 8 of the 128-byte batch (eight lanes = one full line of a row)
+    const int srow = tid >> 3, scol = tid & 7;
+    const unsigned char *gI = cd.XM + (size_t)(ti * BNR_GT + srow) * cd.kslab + (size_t)ks * cd.kcp + 16 * scol;
+    const unsigned char *gJ = cd.XM + (size_t)(tj * BNR_GT + srow) * cd.kslab + (size_t)ks * cd.kcp + 16 * scol;
+    const size_t r32 = (size_t)32 * cd.kslab;
+    const int soff = srow * BNR_I8_RS + 16 * scol;
+    bnr_i4 r0 = {0, 0, 0, 0}, r1 = r0, r2 = r0, r3 = r0;
+    const int nbatch = cd.kcp / 128, nb = nbatch + ((cd.kcp % 128) ? 1 : 0);       // kcp is a multiple of 64: a last HALF batch is possible
+    auto load = [&](int b) {
+        const int o = 128 * b;
+        if (b < nbatch || scol < 4) { r0 = *(const bnr_i4 *)(gI + o); r1 = *(const bnr_i4 *)(gI + r32 + o); r2 = *(const bnr_i4 *)(gJ + o); r3 = *(const bnr_i4 *)(gJ + r32 + o); }
+    };
+    auto store = [&](int buf) {
+        unsigned char *d = sX + buf * 2 * BNR_I8_TB + soff;
+        *(bnr_i4 *)d = r0; *(bnr_i4 *)(d + 32 * BNR_I8_RS) = r1; *(bnr_i4 *)(d + BNR_I8_TB) = r2; *(bnr_i4 *)(d + BNR_I8_TB + 32 * BNR_I8_RS) = r3;
+    };
+    // wave w: the 16 i rows 16 w .. 16 w + 15 (ONE masked B fragment per digit plane) x all 64 j rows (four A fragments, the raw mask = -x)
+    bnr_i4 acc[L][4];
 #pragma unroll
     for (int l = 0; l < L; ++l)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 4; ++a) acc[l][a] = bnr_i4{0, 0, 0, 0};
+    load(0); store(0);
+    if (nb > 1) load(1);
+    __syncthreads();
+    const int fa = ln * BNR_I8_RS + 16 * lq + BNR_I8_TB, fb = (wave * 16 + ln) * BNR_I8_RS + 16 * lq;
+    for (int b = 0; b < nb; ++b) {
+        const unsigned char *xb = sX + (b & 1) * 2 * BNR_I8_TB;
+        const int nk = (b < nbatch) ? 2 : 1;
+        for (int kk = 0; kk < nk; ++kk) {
+            const bnr_i4 a0 = *(const bnr_i4 *)(xb + fa + 64 * kk), a1 = *(const bnr_i4 *)(xb + fa + 16 * BNR_I8_RS + 64 * kk);
+            const bnr_i4 a2 = *(const bnr_i4 *)(xb + fa + 32 * BNR_I8_RS + 64 * kk), a3 = *(const bnr_i4 *)(xb + fa + 48 * BNR_I8_RS + 64 * kk);
+            const bnr_i4 b0 = *(const bnr_i4 *)(xb + fb + 64 * kk);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[l][a][b] = bnr_i4{0, 0, 0, 0};
-    const int nstep = cd.kcp / 64;
-    bnr_i4 a0 = *(const bnr_i4 *)pa0, a1 = *(const bnr_i4 *)(pa0 + r16), b0 = *(const bnr_i4 *)pb0, b1 = *(const bnr_i4 *)(pb0 + r16);
-    for (int st = 0; st < nstep; ++st) {
-        bnr_i4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
-        if (st + 1 < nstep) {
-            const int o = 64 * (st + 1);
-            na0 = *(const bnr_i4 *)(pa0 + o); na1 = *(const bnr_i4 *)(pa0 + r16 + o); nb0 = *(const bnr_i4 *)(pb0 + o); nb1 = *(const bnr_i4 *)(pb0 + r16 + o);
+            for (int l = 0; l < L; ++l) {
+                const bnr_i4 m0 = b0 & sDig[l * ng + (2 * b + kk) * 4 + lq];
+                acc[l][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, m0, acc[l][0], 0, 0, 0);
+                acc[l][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, m0, acc[l][1], 0, 0, 0);
+                acc[l][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, m0, acc[l][2], 0, 0, 0);
+                acc[l][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, m0, acc[l][3], 0, 0, 0);
+            }
+            if (kk == 0 && b + 1 < nb) { store((b + 1) & 1); if (b + 2 < nb) load(b + 2); }   // batch b+1 into the buffer the last barrier released, batch b+2 into the registers
         }
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const bnr_i4 dg = sDig[l * ng + st * 4 + lq];
-            const bnr_i4 m0 = b0 & dg, m1 = b1 & dg;
-            acc[l][0][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, m0, acc[l][0][0], 0, 0, 0);
-            acc[l][0][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, m1, acc[l][0][1], 0, 0, 0);
-            acc[l][1][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, m0, acc[l][1][0], 0, 0, 0);
-            acc[l][1][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, m1, acc[l][1][1], 0, 0, 0);
-        }
-        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        __syncthreads();
     }
-    // acc[l][jt][it][r]: j = wj 32 + jt 16 + 4 lq + r, i = wi 32 + it 16 + ln, holding -T_l (the A operand was -x); tile element (i, j) at [j 64 + i]
+    // acc[l][jt][r]: j = jt 16 + 4 lq + r, i = 16 wave + ln, holding -T_l (the A operand was -x); tile element (i, j) at [j 64 + i]
     const double sc = -cd.scal[SC_I8SCALE];
     double *out = cd.Gpart + ((size_t)ks * ntl + t) * (BNR_GT * BNR_GT);
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int it = 0; it < 2; ++it)
+        for (int r = 0; r < 4; ++r) {
+            double v = (double)acc[0][jt][r];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double v = (double)acc[0][jt][it][r];
-#pragma unroll
-                for (int l = 1; l < L; ++l) v = v * 128.0 + (double)acc[l][jt][it][r];
-                out[(wj * 32 + jt * 16 + 4 * lq + r) * BNR_GT + wi * 32 + it * 16 + ln] = v * sc;
-            }
+            for (int l = 1; l < L; ++l) v = v * 256.0 + (double)acc[l][jt][r];
+            out[(jt * 16 + 4 * lq + r) * BNR_GT + wave * 16 + ln] = v * sc;
+        }
 }
 
 // E = extended matrix of the factorization, (2 n_pad + 32) x n_pad, column-major, leading dimension ldE:

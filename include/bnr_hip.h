@@ -264,8 +264,8 @@ int bnr_debug_set_exp(int32_t device, int32_t flags);
  *   "gram_i8"   (chains only; round 5) 1 (the default from n_pad^2 q >= 2.5e8 on, where it was measured faster -- n = 500, V = 100 and
  *               larger; smaller problems default to 0): the model matrix came integer-typed with every entry 0 or 1
  *               (the reference's adjacency data, docs/src/man/inputdata.md:5-10) -- its Gram X diag(S) X' (gibbs.jl:434) runs on the i8 matrix pipe:
- *               S as i8L = 7..9 planes of 7-bit digits under the exponent of its largest entry (k_sdigits), one exact i32 Gram per plane
- *               (k_gram_i8, v_mfma_i32_16x16x64_i8), recombined in f64.  |G_i8 - G_exact| <= 2 q 2^(-7 i8L) max S <= 1e-12 max |G|; the tables
+ *               S as i8L = 7 or 8 planes of balanced base-256 digits under the exponent of its largest entry (k_sdigits), one exact i32 Gram per plane
+ *               (k_gram_i8, v_mfma_i32_16x16x64_i8), recombined in f64.  |G_i8 - G_exact| <= 8 q 2^(-8 i8L) max S <= 1e-12 max |G|; the tables
  *               agree with the f64 Gram's to that size of perturbation (NOT bit for bit) and with the oracle to the same 1e-6 as everything
  *               else.  0: the f64 Gram also for a binary matrix.  A matrix that is not binary has no i8 path (setting 1 is refused).
  *               bnr_chain_last_timing(which = 4): *avg_us = 1 when the chain's (its group's) Gram runs on the i8 pipe, *launches = i8L.

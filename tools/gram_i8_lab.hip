@@ -22,7 +22,7 @@ struct args_t {
     int n_pad, q, kslab, kcp, kchunk, ksplit, ntile, nchains;
 };
 
-template <int L>
+template <int L, bool BAL = false>
 __global__ __launch_bounds__(1024) void k_sdigits(const args_t A)
 {
     const int c = blockIdx.x, tid = threadIdx.x;
@@ -37,16 +37,118 @@ __global__ __launch_bounds__(1024) void k_sdigits(const args_t A)
     for (int w = 1; w < 16; ++w) m = fmax(m, red[w]);
     int e;
     (void)frexp(m, &e);                                   // m = f 2^e, f in [0.5, 1): every S < 2^e
-    const double up = ldexp(1.0, 7 * L - e);              // S * up < 2^(7 L)
-    if (tid == 0) A.scale[c][0] = ldexp(1.0, e - 7 * L);
+    // plain: 7-bit digits 0..127, S up < 2^(7 L).  balanced: base-256 digits -128..127 (one plane fewer for the same bits): S up < 2^(8 L - 2), the top digit stays below 64
+    const int bits = BAL ? 8 * L - 2 : 7 * L;
+    const double up = ldexp(1.0, bits - e);
+    if (tid == 0) A.scale[c][0] = ldexp(1.0, e - bits);
     unsigned char *D = A.D[c];
     for (int idx = tid; idx < A.kslab; idx += 1024) {
         const int ks = idx / A.kcp, kk = idx % A.kcp, k = ks * A.kchunk + kk;
         unsigned long long N = 0;
         if (kk < A.kchunk && k < A.q) N = (unsigned long long)(S[k] * up);
+        if (!BAL) {
 #pragma unroll
-        for (int l = 0; l < L; ++l) D[(size_t)l * A.kslab + idx] = (unsigned char)((N >> (7 * (L - 1 - l))) & 127ull);
+            for (int l = 0; l < L; ++l) D[(size_t)l * A.kslab + idx] = (unsigned char)((N >> (7 * (L - 1 - l))) & 127ull);
+        } else {
+            // least significant digit first: a byte >= 128 becomes byte - 256 and carries one into the next
+            unsigned carry = 0;
+#pragma unroll
+            for (int l = L - 1; l >= 0; --l) {
+                unsigned b = (unsigned)((N >> (8 * (L - 1 - l))) & 255ull) + carry;
+                carry = b >= 128u ? 1u : 0u;
+                D[(size_t)l * A.kslab + idx] = (unsigned char)(b & 255u);          // two's complement byte of b - 256 carry
+            }
+        }
     }
+}
+
+// version 2: X tiles staged through LDS (full 128-byte lines, each byte fetched once per workgroup instead of once per wave pair), two k-steps per
+// batch, double buffered; balanced base-256 digits (BAL) one plane fewer.  Row stride 144 bytes: conflict-free ds_read_b128 fragments.
+template <int L, bool BAL, int EXP = 0>
+__global__ __launch_bounds__(256, 2) void k_gram_i8v2(const args_t A)
+{
+    const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
+    const int chain = gr % A.nchains, slot = (gr / A.nchains) * 8 + gx;
+    const int ntl = A.ntile * (A.ntile + 1) / 2;
+    if (slot >= ntl * A.ksplit) return;
+    const int ks = slot % A.ksplit, t = slot / A.ksplit;
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    constexpr int RS = 144;                                 // bytes per staged row (128 + 16 pad)
+    constexpr int TB = 64 * RS;                             // one 64-row tile of a batch
+    extern __shared__ i4 smem[];
+    unsigned char *sX = (unsigned char *)smem;              // [buf][I | J][64 rows][144]
+    i4 *sD = (i4 *)(sX + 4 * TB);                           // digits: [l][kcp / 16]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ln = lane & 15, lq = lane >> 4;
+    const int wi = (wave >> 1) & 1, wj = wave & 1;
+    const int ng = A.kcp / 16;
+    for (int idx = tid; idx < L * ng; idx += 256) {
+        const int l = idx / ng, g = idx % ng;
+        sD[idx] = *(const i4 *)(A.D[chain] + (size_t)l * A.kslab + (size_t)ks * A.kcp + 16 * g);
+    }
+    // staging map: thread -> row tid / 8 (+ 32), 16-byte column tid % 8 of the 128-byte batch
+    const int srow = tid >> 3, scol = tid & 7;
+    const unsigned char *gI = A.XM + (size_t)(ti * 64 + srow) * A.kslab + (size_t)ks * A.kcp + 16 * scol;
+    const unsigned char *gJ = A.XM + (size_t)(tj * 64 + srow) * A.kslab + (size_t)ks * A.kcp + 16 * scol;
+    const size_t r32 = (size_t)32 * A.kslab;
+    const int soff = srow * RS + 16 * scol;
+    i4 r0 = {0, 0, 0, 0}, r1 = r0, r2 = r0, r3 = r0;
+    const int nbatch = A.kcp / 128, tailstep = (A.kcp % 128) / 64;        // kcp is a multiple of 64: a last half batch is possible
+    const int nb = nbatch + (tailstep ? 1 : 0);
+    auto load = [&](int b) {
+        const int o = 128 * b;
+        if (b < nbatch || scol < 4) { r0 = *(const i4 *)(gI + o); r1 = *(const i4 *)(gI + r32 + o); r2 = *(const i4 *)(gJ + o); r3 = *(const i4 *)(gJ + r32 + o); }
+    };
+    auto store = [&](int buf) {
+        unsigned char *d = sX + buf * 2 * TB + soff;
+        *(i4 *)d = r0; *(i4 *)(d + 32 * RS) = r1; *(i4 *)(d + TB) = r2; *(i4 *)(d + TB + 32 * RS) = r3;
+    };
+    // wave w: the 16 i rows 16 w .. 16 w + 15 (ONE masked B fragment per digit plane) x all 64 j rows (four A fragments): one mask per four MFMAs
+    i4 acc[L][4];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[l][a] = i4{0, 0, 0, 0};
+    load(0); store(0);
+    if (nb > 1) load(1);
+    __syncthreads();
+    // fragment addresses inside a buffer: row * 144 + 64 kk + 16 lq; J tile behind the I tile
+    const int fa = ln * RS + 16 * lq + TB, fb = (wave * 16 + ln) * RS + 16 * lq;
+    (void)wi; (void)wj;
+    for (int b = 0; b < nb; ++b) {
+        const unsigned char *xb = sX + (b & 1) * 2 * TB;
+        const int nk = (b < nbatch) ? 2 : 1;
+        for (int kk = 0; kk < nk; ++kk) {
+            const i4 a0 = *(const i4 *)(xb + fa + 64 * kk), a1 = *(const i4 *)(xb + fa + 16 * RS + 64 * kk);
+            const i4 a2 = *(const i4 *)(xb + fa + 32 * RS + 64 * kk), a3 = *(const i4 *)(xb + fa + 48 * RS + 64 * kk);
+            const i4 b0 = *(const i4 *)(xb + fb + 64 * kk);
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const i4 d = sD[l * ng + (2 * b + kk) * 4 + lq];
+                const i4 m0 = (EXP & 2) ? b0 : (b0 & d);
+                acc[l][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, m0, acc[l][0], 0, 0, 0);
+                acc[l][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, m0, acc[l][1], 0, 0, 0);
+                acc[l][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, m0, acc[l][2], 0, 0, 0);
+                acc[l][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, m0, acc[l][3], 0, 0, 0);
+            }
+            if (kk == 0 && b + 1 < nb) { store((b + 1) & 1); if (b + 2 < nb && !(EXP & 1)) load(b + 2); }
+        }
+        __syncthreads();
+    }
+    // acc[l][jt][r]: j = jt 16 + 4 lq + r, i = 16 wave + ln
+    const double sc = -A.scale[chain][0];
+    const double base = BAL ? 256.0 : 128.0;
+    double *out = A.G[chain] + ((size_t)ks * ntl + t) * 4096;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double v = (double)acc[0][jt][r];
+#pragma unroll
+            for (int l = 1; l < L; ++l) v = v * base + (double)acc[l][jt][r];
+            out[(jt * 16 + 4 * lq + r) * 64 + wave * 16 + ln] = v * sc;
+        }
 }
 
 template <int L, int EXP = 0>
@@ -118,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void k_gram_i8(const args_t A)
             }
 }
 
-template <int L, int EXP = 0>
+template <int L, int EXP = 0, int VER = 1, bool BAL = false>
 static void run(int n, int V, int nchains, int ksplit, double srange)
 {
     const int q = V * (V + 1) / 2, n_pad = (n + 63) / 64 * 64, ntile = n_pad / 64, ntl = ntile * (ntile + 1) / 2;
@@ -142,13 +244,15 @@ static void run(int n, int V, int nchains, int ksplit, double srange)
     }
     const int grid = (ntl * ksplit + 7) / 8 * 8 * nchains;
     hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
-    for (int i = 0; i < 3; ++i) { k_sdigits<L><<<nchains, 1024>>>(A); k_gram_i8<L, EXP><<<grid, 256, (size_t)L * kcp>>>(A); }
+    const size_t lds2 = (size_t)4 * 64 * 144 + (size_t)L * kcp;
+#define GRAM_LAUNCH() do { if (VER == 1) k_gram_i8<L, EXP><<<grid, 256, (size_t)L * kcp>>>(A); else k_gram_i8v2<L, BAL, EXP><<<grid, 256, lds2>>>(A); } while (0)
+    for (int i = 0; i < 3; ++i) { k_sdigits<L, BAL><<<nchains, 1024>>>(A); GRAM_LAUNCH(); }
     CK(hipDeviceSynchronize());
     const int reps = 30;
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) k_sdigits<L><<<nchains, 1024>>>(A);
+    for (int i = 0; i < reps; ++i) k_sdigits<L, BAL><<<nchains, 1024>>>(A);
     CK(hipEventRecord(e1));
-    for (int i = 0; i < reps; ++i) k_gram_i8<L, EXP><<<grid, 256, (size_t)L * kcp>>>(A);
+    for (int i = 0; i < reps; ++i) GRAM_LAUNCH();
     CK(hipEventRecord(e2)); CK(hipDeviceSynchronize());
     float ms0, ms1; CK(hipEventElapsedTime(&ms0, e0, e1)); CK(hipEventElapsedTime(&ms1, e1, e2));
     // check against the plain f64 sum on sampled entries, relative to max |G|
@@ -173,8 +277,8 @@ static void run(int n, int V, int nchains, int ksplit, double srange)
         for (double e : errs) worst = std::max(worst, e / gmax);
         (void)smax;
     }
-    printf("EXP=%d n=%d V=%d q=%d  %d chains  L=%d slices  ksplit %d (kchunk %d, padded %d)  S range e^+-%.0f:  digits %.2f us  Gram %.2f us per launch   worst |err| / max|G| = %.2e (bound q 2^(1-7L) = %.2e)\n",
-           EXP, n, V, q, nchains, L, ksplit, kchunk, kcp, srange, ms0 * 1e3 / reps, ms1 * 1e3 / reps, worst, q * ldexp(1.0, 1 - 7 * L));
+    printf("v%d%s EXP=%d n=%d V=%d q=%d  %d chains  L=%d slices  ksplit %d (kchunk %d, padded %d)  S range e^+-%.0f:  digits %.2f us  Gram %.2f us per launch   worst |err| / max|G| = %.2e (bound q 2^(1-7L) = %.2e)\n",
+           VER, BAL ? " balanced" : "", EXP, n, V, q, nchains, L, ksplit, kchunk, kcp, srange, ms0 * 1e3 / reps, ms1 * 1e3 / reps, worst, BAL ? 8.0 * q * ldexp(1.0, -8 * L) : q * ldexp(1.0, 1 - 7 * L));
     fflush(stdout);
     CK(hipFree(dXM));
     for (int c = 0; c < nchains; ++c) { CK(hipFree(dS[c])); CK(hipFree(dG[c])); CK(hipFree(dsc[c])); CK(hipFree(dD[c])); }
@@ -182,6 +286,14 @@ static void run(int n, int V, int nchains, int ksplit, double srange)
 
 int main()
 {
+    if (getenv("LAB_V2")) {
+        run<8, 0, 1>(500, 100, 8, 7, 3.0); run<8, 0, 2>(500, 100, 8, 7, 3.0); run<7, 0, 2, true>(500, 100, 8, 7, 3.0); run<7, 0, 2, true>(500, 100, 8, 7, 30.0);
+        run<7, 1, 2, true>(500, 100, 8, 7, 3.0); run<7, 2, 2, true>(500, 100, 8, 7, 3.0);
+        run<8, 0, 1>(500, 100, 1, 7, 3.0); run<7, 0, 2, true>(500, 100, 1, 7, 3.0);
+        run<9, 0, 1>(500, 300, 8, 48, 3.0); run<8, 0, 2, true>(500, 300, 8, 48, 3.0); run<8, 0, 2, true>(500, 300, 1, 48, 3.0);
+        run<7, 0, 2, true>(70, 19, 8, 1, 3.0); run<7, 0, 2, true>(130, 40, 3, 2, 3.0);
+        return 0;
+    }
     if (getenv("LAB_ABLATE")) {
         run<8, 0>(500, 100, 8, 7, 3.0); run<8, 1>(500, 100, 8, 7, 3.0); run<8, 2>(500, 100, 8, 7, 3.0); run<8, 4>(500, 100, 8, 7, 3.0); run<8, 7>(500, 100, 8, 7, 3.0);
         run<9, 0>(500, 300, 8, 48, 3.0); run<9, 1>(500, 300, 8, 48, 3.0); run<9, 2>(500, 300, 8, 48, 3.0); run<9, 7>(500, 300, 8, 48, 3.0);
