@@ -1,11 +1,12 @@
 """Randomised parity sweep: random (n, V, R, seed, X flavour, hyper-parameters), a few Gibbs sweeps on the GPU (alone or as a
-member of a lockstep group) against the CPU oracle on identical variates.  usage: fuzz_shapes.py <cases> [seed]"""
+member of a lockstep group) against the CPU oracle on identical variates.  usage: fuzz_shapes.py <cases> [seed] [scale | binary]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bnr_amd
 from oracle import bnr_oracle as bo
 N = int(sys.argv[1]); rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 SCALE = len(sys.argv) > 3 and sys.argv[3] == "scale"
+BINARY = len(sys.argv) > 3 and sys.argv[3] == "binary"     # Bool model matrix, the Gram forced onto the i8 matrix pipe (round 5) whatever the size
 worst_all = 0.0
 for case in range(N):
     V = int(rng.integers(2, 41)); R = int(rng.integers(1, 13)); n = int(rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200, int(rng.integers(4, 260)), int(rng.integers(260, 700))]))
@@ -16,9 +17,17 @@ for case in range(N):
     if SCALE:                                                  # badly scaled data: X and y over several orders of magnitude
         sx, sy = 10.0 ** rng.integers(-3, 4), 10.0 ** rng.integers(-3, 4)
         X = np.asfortranarray(X * sx); y = y * sy
-    ch = bnr_amd.Chain(X, y, R, tot, seed, 1, **hyper)
+    if BINARY:
+        Xb = np.asfortranarray(rng.random(X.shape) < float(rng.choice([0.5, 0.1, 0.9])))
+        X = np.asfortranarray(Xb.astype(np.float64))           # what the oracle sees
+    ch = bnr_amd.Chain(bnr_amd.XInput(Xb, False) if BINARY else X, y, R, tot, seed, 1, **hyper)
+    if BINARY:
+        ch.set_option("gram_i8", 1)
+        assert ch.last_timing(4)[0] == 1
     gsize = int(rng.integers(2, 8))
     mates = [bnr_amd.Chain.like(ch, seed, c, tot) for c in range(2, gsize + 1)] if group else []
+    if BINARY:
+        for c in mates: c.set_option("gram_i8", 1)
     for c in [ch] + mates: c.init_prior()
     g = bnr_amd.Group(mates[:1] + [ch] + mates[1:]) if group else None
     (g or ch).run(2, tot, tot)
@@ -47,4 +56,4 @@ for case in range(N):
     if g: g.close()
     for c in [ch] + mates: c.close()
     if case % 20 == 19: print("case %d ok (n=%d V=%d R=%d group=%s), worst so far %.2e" % (case + 1, n, V, R, group, worst_all), flush=True)
-print("all %d cases within %s of the oracle (worst relative error %.2e); discrete columns equal" % (N, "max(1e-6, 30 x the oracle's own LU-vs-Cholesky drift)" if SCALE else "1e-6", worst_all))
+print(("BINARY model matrices, Gram on the i8 pipe: " if BINARY else "") + "all %d cases within %s of the oracle (worst relative error %.2e); discrete columns equal" % (N, "max(1e-6, 30 x the oracle's own LU-vs-Cholesky drift)" if SCALE else "1e-6", worst_all))
