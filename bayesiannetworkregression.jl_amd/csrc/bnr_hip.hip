@@ -803,6 +803,14 @@ static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
     // update workgroups: one 32 x 32 block each while panels + updates of all members fit the chip in one round (two 256-thread
     // workgroups per CU); otherwise (large n, groups) 64 x 64 super blocks
     const int ncu = x.ncu, fuse0 = reduce_in_chol(x) ? 1 : 0;
+    // groups of up to 8: the steps that need only E / n_pad / counters get them by value in the kernel arguments (bnr_few)
+    // (measured: 384.5 -> 381.6 us per sweep of 8 chains, profiles/round5_experiments_notes.txt G)
+    const bool few_ok = x.nb >= 2 && x.nb <= 8 && x.cds_pin;
+    bnr_few few{};
+    if (few_ok) {
+        for (int i = 0; i < 8; ++i) { const bnr_dev &m = x.cds_pin[i < x.nb ? i : 0]; few.E[i] = m.E; few.counters[i] = m.counters; few.dbg[i] = m.dbg; }
+        few.n_pad = x.shape->n_pad;
+    }
     for (int p = 0; p < nbk; ++p) {
         const int npan = bnr_chol_npanel(nbk, p), ntile = bnr_chol_ntile(nbk, p);
         if (p == 0 && fuse0) {
@@ -819,9 +827,11 @@ static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
             // bandwidth-bound and wants every workgroup in flight at once: n=2000 408 vs 421 it/s)
             const int freecu = ncu - x.nb * npan;
             const int spw = (freecu > 0 && nbk <= 24) ? std::min(x.spw_cap, std::max(1, (x.nb * nsup + freecu - 1) / freecu)) : 1;
-            BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + (nsup + spw - 1) / spw), dim3(256), 0, st, x, p, s, 0, spw, fuse0);
+            if (few_ok && p >= 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_step<bnr_few>), dim3(x.nb, npan + (nsup + spw - 1) / spw), dim3(256), 0, st, few, p, s, 0, spw, fuse0);
+            else BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + (nsup + spw - 1) / spw), dim3(256), 0, st, x, p, s, 0, spw, fuse0);
         } else {
-            BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + ntile), dim3(256), 0, st, x, p, s, 1, 1, fuse0);
+            if (few_ok && p >= 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_step<bnr_few>), dim3(x.nb, npan + ntile), dim3(256), 0, st, few, p, s, 1, 1, fuse0);
+            else BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + ntile), dim3(256), 0, st, x, p, s, 1, 1, fuse0);
         }
     }
 }

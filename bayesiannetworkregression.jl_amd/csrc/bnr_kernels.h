@@ -113,6 +113,25 @@ struct bnr_many {
     __device__ __forceinline__ bnr_dev get_x() const { return bnr_globalized(p + blockIdx.x); }
     __device__ __forceinline__ bnr_dev at(int c) const { return bnr_globalized(p + c); }
 };
+// A lockstep group of at most 8 chains, for the kernels that need next to nothing of a chain's descriptor (the panel steps p >= 2 of the factorization: E,
+// n_pad, the failure counters): those few words travel BY VALUE in the kernel arguments, indexed by the grid's chain coordinate -- one scalar load from
+// the kernarg segment instead of "load the descriptor's address, then load the descriptor" in front of the first useful load (a panel step is a chain of
+// a few dependent round trips: one fewer is ~0.4 us per step, 16 steps per sweep).
+struct bnr_few {
+    double *E[8];
+    long long *counters[8];
+    unsigned long long *dbg[8];
+    int n_pad;
+    __device__ __forceinline__ bnr_dev get_x() const
+    {
+        bnr_dev d{};
+        d.E = E[blockIdx.x]; d.counters = counters[blockIdx.x]; d.dbg = dbg[blockIdx.x]; d.n_pad = n_pad;
+        BNR_GLOBAL_PTR(E); BNR_GLOBAL_PTR(counters); BNR_GLOBAL_PTR(dbg);
+        return d;
+    }
+    __device__ __forceinline__ bnr_dev get() const { return get_x(); }
+    __device__ __forceinline__ bnr_dev at(int) const { return get_x(); }
+};
 
 #define BNR_EXP_SKIP_SCALAR() 0
 #define BNR_EXP_SKIP_CHOL(p) 0
