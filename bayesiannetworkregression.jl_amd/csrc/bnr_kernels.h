@@ -1211,8 +1211,9 @@ __device__ __forceinline__ bnr_d4 bnr_tile_update(const double *colrows, const d
 #ifndef BNR_SWEEP_RL
 #define BNR_SWEEP_RL 1
 #endif
-template <int COFF>
-__device__ __forceinline__ int bnr_sweep16(double (&a)[16], int lane, double (*sCol)[BNR_NB])
+#define BNR_L1S 80            // LDS column stride of the 64 x 16 half-panel handed to the MFMA update (conflict-free fragments)
+template <int COFF, bool PUB = false>
+__device__ __forceinline__ int bnr_sweep16(double (&a)[16], int lane, double (*sCol)[BNR_NB], double *pub = nullptr)
 {
     int bad = 0;
     double lprev = 0.0;
@@ -1254,6 +1255,7 @@ __device__ __forceinline__ int bnr_sweep16(double (&a)[16], int lane, double (*s
         piv = fma(-t1, t1, s1);                          // next pivot
         double lj = a[j] * rinv;
         a[j] = lj;
+        if (PUB) pub[j * BNR_L1S + lane] = lj;             // the finished column goes to LDS at once (an LDS write costs the chain nothing) instead of 16 writes behind the sweep
         if (j + 1 < 16) a[j + 1] = fma(-lj, t1, a[j + 1]);
         if (j + 2 < 16) a[j + 2] = fma(-lj, s3 * rinv, a[j + 2]);
 #if !BNR_SWEEP_RL
@@ -1271,7 +1273,6 @@ __device__ __forceinline__ int bnr_sweep16(double (&a)[16], int lane, double (*s
     return bad;
 }
 
-#define BNR_L1S 80            // LDS column stride of the 64 x 16 half-panel handed to the MFMA update (conflict-free fragments)
 struct bnr_panel_lds {
     double sD[BNR_NB * BNR_LP], sB[BNR_NB * BNR_LP];
     double sCol[2][BNR_NB];
@@ -1308,10 +1309,8 @@ __device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &
 #pragma unroll
         for (int c = 0; c < 16; ++c) a1[c] = src[rr + BNR_LP * c];
         BNR_PH(2);
-        bad = bnr_sweep16<0>(a1, lane, sh.sCol);
+        bad = bnr_sweep16<0, true>(a1, lane, sh.sCol, sh.sL1);
         BNR_PH(3);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) sh.sL1[c * BNR_L1S + lane] = a1[c];
     }
     __syncthreads();
     BNR_PH(4);
@@ -1322,12 +1321,14 @@ __device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &
         bnr_d4 c;
 #pragma unroll
         for (int r = 0; r < 4; ++r) c[r] = sx[(rowb + ln) + BNR_LP * (16 + lq + 4 * r)];
+        double av[4], bv[4];                                                   // all eight fragments in flight before the chain of four dependent MFMAs
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            double av = sh.sL1[(4 * ks + lq) * BNR_L1S + 16 + ln];            // column side: rows 16..31 of the diagonal part
-            double bv = sh.sL1[(4 * ks + lq) * BNR_L1S + 16 * wave + ln];     // row side
-            c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av, bv, c, 0, 0, 0);
+            av[ks] = sh.sL1[(4 * ks + lq) * BNR_L1S + 16 + ln];               // column side: rows 16..31 of the diagonal part
+            bv[ks] = sh.sL1[(4 * ks + lq) * BNR_L1S + 16 * wave + ln];        // row side
         }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[ks], bv[ks], c, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) sx[(rowb + ln) + BNR_LP * (16 + lq + 4 * r)] = c[r];
     }
