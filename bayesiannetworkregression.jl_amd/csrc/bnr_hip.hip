@@ -844,7 +844,8 @@ static void launch_backproj(bnr_exec &x, int s, int flags)
 {
     size_t lds = std::max<size_t>(x.shape->n_pad + 64, (size_t)(3 * x.shape->R + 1) * 33) * sizeof(double);
     const int nslot = (x.nb * x.shape->nblk_bp <= 2 * x.ncu) ? 8 : 2;    // speculative GIG attempts per edge and round
-    BNR_LAUNCH(k_backproj, dim3(round_up(x.shape->nblk_bp, 8) * x.nb), dim3(256), lds, x.stream, x, s, flags, x.nb, nslot);
+    const int wide = (x.nb == 1 || x.shape->nblk_bp >= 1024) ? 256 : 0;    // four columns of X per wave and trip (see the kernel)
+    BNR_LAUNCH(k_backproj, dim3(round_up(x.shape->nblk_bp, 8) * x.nb), dim3(256), lds, x.stream, x, s, flags | wide, x.nb, nslot);
 }
 static void launch_tail(bnr_exec &x, int s, int mask, int xg_src)
 { BNR_LAUNCH(k_tail, dim3(1, 1, x.nb), dim3(BNR_TAIL_THREADS), (size_t)x.shape->R * x.shape->V * sizeof(double), x.stream, x, s, mask, xg_src); }

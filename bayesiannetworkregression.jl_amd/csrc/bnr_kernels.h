@@ -2026,6 +2026,28 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
     if (flags & 1) {
         for (int i = tid; i < cd.n_pad; i += blockDim.x) sa[i] = cd.a4[i];
         __syncthreads();
+        // four columns of X per wave and trip where the host asks for it (flags bit 8; round 5: launches of one chain and large q -- one chain at the headline
+        // shape 184.3 -> 182.5 us per sweep, config 5 x 8 chains 2 127 -> 2 103; the headline group of 8 stays at two: 380.5 vs 382.6): twice the loads in flight
+        // per wave, half the dependent trips through memory -- every column's dot product is accumulated over the rows in the same order either way (bitwise
+        // the same gamma)
+        if (flags & 256)
+        for (int t = wave; t < ne; t += 16) {
+            const int t2 = t + 4, t3 = t + 8, t4 = t + 12;
+            const size_t oc = (size_t)(e0 + t) * ld, od = (size_t)(e0 + (t2 < ne ? t2 : t)) * ld, oe = (size_t)(e0 + (t3 < ne ? t3 : t)) * ld, of = (size_t)(e0 + (t4 < ne ? t4 : t)) * ld;
+            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+            if (cd.X8) {
+                const unsigned char *xc = cd.X8 + oc, *xd = cd.X8 + od, *xe = cd.X8 + oe, *xf = cd.X8 + of;
+#pragma unroll 4
+                for (int i = lane; i < cd.n_pad; i += 64) { double av = sa[i]; acc0 = fma((double)xc[i], av, acc0); acc1 = fma((double)xd[i], av, acc1); acc2 = fma((double)xe[i], av, acc2); acc3 = fma((double)xf[i], av, acc3); }
+            } else {
+                const double *xc = cd.X + oc, *xd = cd.X + od, *xe = cd.X + oe, *xf = cd.X + of;
+#pragma unroll 4
+                for (int i = lane; i < cd.n_pad; i += 64) { double av = sa[i]; acc0 = fma(xc[i], av, acc0); acc1 = fma(xd[i], av, acc1); acc2 = fma(xe[i], av, acc2); acc3 = fma(xf[i], av, acc3); }
+            }
+            acc0 = wave_sum(acc0); acc1 = wave_sum(acc1); acc2 = wave_sum(acc2); acc3 = wave_sum(acc3);
+            if (lane == 0) { sdot[t] = acc0; if (t2 < ne) sdot[t2] = acc1; if (t3 < ne) sdot[t3] = acc2; if (t4 < ne) sdot[t4] = acc3; }
+        }
+        else
         for (int t = wave; t < ne; t += 8) {
             const int t2 = t + 4;
             const size_t oc = (size_t)(e0 + t) * ld, od = (size_t)(e0 + (t2 < ne ? t2 : t)) * ld;
