@@ -69,7 +69,7 @@ struct bnr_exec {
     int split_sums = -1;                                 // 1: the back-projection's partial sums as a launch of their own in front of the scalar tail (off the critical chain)
     int spw_cap = 4;                                    // super blocks per update workgroup of the factorization, at most
     int factor_variant = -1;                            // -1: chosen by size; 0: right-looking k_chol_step (+ k_gram_reduce); 1: left-looking k_chol_ll
-    int use_graph = 1, graph_k = 8;
+    int use_graph = 1, graph_k = 16;                     // (round 5: 16, was 8 -- between two graph launches the GPU idles ~30 us: 640 sweeps 382.2 -> 380.1 us each, 20 sweeps = 16 + 4 instead of 8 + 8 + 4)
     struct rung { int k; hipGraph_t graph; hipGraphExec_t gexec; };
     std::vector<rung> ladder;                           // captured graphs of graph_k, graph_k/2, ..., 1 sweeps: any batch is replayed
     bnr_dev *cds_pin = nullptr;                         // pinned staging of the members' descriptors

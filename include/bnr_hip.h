@@ -239,7 +239,7 @@ int bnr_debug_set_exp(int32_t device, int32_t flags);
 
 /* tunables (performance only; never change results):
  *   "graph"     1 (default): replay captured hipGraphs of graph_k sweeps; 0: launch every kernel eagerly
- *   "graph_k"   sweeps per captured graph (default 8)
+ *   "graph_k"   sweeps per captured graph (default 16; a ladder graph_k, graph_k / 2, ..., 1 is captured so that a batch of any length is pure replay)
  *   "overlap"   1 (default): scalar branch and Gram/factorization branch of a sweep on two streams; 0: one stream
  *   "gram_variant" 0 (default): the Gram kernel is chosen per launch (k_gram8 when the launch has more than two workgroups per CU,
  *               k_gram otherwise); 8 / 16 force one of them.  Both write the same partial tiles bit for bit.  (9..14: the persistent /
