@@ -400,7 +400,10 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
         d.XM = nullptr;
         {
             const char *off8 = getenv("BNR_NO_GRAM_I8");
-            if (X8 && !(off8 && atoi(off8))) {
+            // k_gram_i8 keeps the digits of a whole K slice in LDS beside its staging buffers: beyond 64 KiB of dynamic LDS (q in the hundreds of
+            // thousands with the K split capped at 32) there is no i8 path -- the f64 Gram runs as for any other matrix
+            const bool fits = bnr_i8_lds_bytes(d.i8L, d.kcp) <= (size_t)64 * 1024;
+            if (X8 && fits && !(off8 && atoi(off8))) {
                 unsigned char *XM = nullptr;
                 int *nbin = nullptr;
                 TRY(in_alloc((void **)&XM, (size_t)d.n_pad * d.kslab));
