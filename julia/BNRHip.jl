@@ -87,6 +87,9 @@ function chain_like(donor::Chain, seed, c, tot_save=donor.tot)
 end
 
 init_prior!(ch::Chain) = check(ccall((:bnr_chain_init_prior, LIB), Cint, (Ptr{Cvoid},), ch.h))
+# performance / path options of a chain (include/bnr_hip.h: "byte_x", "gram_i8", "graph", "graph_k", "overlap", ...): e.g. set_option!(ch, "gram_i8", 0) keeps
+# the f64 Gram for a Bool model matrix (the i8 Gram is within 1e-12 max|G| of it, not bitwise)
+set_option!(ch::Chain, name::AbstractString, value::Integer) = check(ccall((:bnr_chain_set_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Int64), ch.h, name, value))
 move_rows!(ch::Chain, to, from, count) = check(ccall((:bnr_chain_move_rows, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Int32), ch.h, to, from, count))
 function resize_table!(ch::Chain, new_tot)
     check(ccall((:bnr_chain_resize, LIB), Cint, (Ptr{Cvoid}, Int32), ch.h, new_tot))
