@@ -3,7 +3,7 @@
 import re, subprocess, sys, os
 here = os.path.dirname(os.path.abspath(__file__))
 src = os.path.join(here, "..", "bayesiannetworkregression.jl_amd", "csrc", "bnr_hip.hip")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form",
        "-Rpass-analysis=kernel-resource-usage", "-shared", "-o", "/tmp/kres.so", src] + sys.argv[1:]
 r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 if r.returncode:
