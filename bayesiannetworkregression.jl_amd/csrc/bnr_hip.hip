@@ -846,7 +846,7 @@ static void launch_solve(bnr_exec &x)
 static void launch_backproj(bnr_exec &x, int s, int flags)
 {
     size_t lds = std::max<size_t>(x.shape->n_pad + 64, (size_t)(3 * x.shape->R + 1) * 33) * sizeof(double);
-    const int nslot = (x.nb * x.shape->nblk_bp <= 2 * x.ncu) ? 8 : 2;    // speculative GIG attempts per edge and round
+    const int nslot = (x.nb * x.shape->nblk_bp <= 2 * x.ncu) ? 8 : 2;    // latency-bound launch: four drawing waves, split by sampler kind; throughput-bound: wave 0 alone (see the kernel)
     const int wide = (x.nb == 1 || x.shape->nblk_bp >= 1024) ? 256 : 0;    // four columns of X per wave and trip (see the kernel)
     BNR_LAUNCH(k_backproj, dim3(round_up(x.shape->nblk_bp, 8) * x.nb), dim3(256), lds, x.stream, x, s, flags | wide, x.nb, nslot);
 }

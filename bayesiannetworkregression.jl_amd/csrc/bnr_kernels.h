@@ -2070,47 +2070,61 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
     // update_D! (gibbs.jl:454-458): the rejection attempts of one GIG draw are independent given their counter, so several
     // attempts of every edge are evaluated side by side (half-wave = 32 edges x one attempt) and the first accepted one is
     // taken -- the same draw as the sequential loop of bnr_gig, in ~1 round instead of 3-5 dependent ones.  nslot (host) = 8
-    // while the launch is latency-bound (few blocks: one chain at moderate q; all four waves, attempts 8 r + 0..7), 2 when
-    // it is throughput-bound (a lockstep group, or q large: wave 0 only) -- speculative attempts that are thrown away then
-    // cost what they save (n=500, V=300: 58 vs 46 us per launch with 8 slots).
+    // while the launch is latency-bound (few blocks: one chain at moderate q; all four waves), 2 when it is throughput-bound
+    // (a lockstep group, or q large: wave 0 only) -- speculative attempts that are thrown away then cost what they save
+    // (n=500, V=300: 58 vs 46 us per launch with 8 slots).
+    // The two rejection samplers (ratio of uniforms / concave envelope: kinds 2 and 3 of bnr_gig_setup) are long, different instruction streams, and the 32
+    // edges of a block usually need both: in ONE wave they run back to back.  The active waves are therefore split by kind -- the first half evaluates setup and
+    // attempts of the kind-2 edges only, the second half those of the kind-3 edges -- and every edge is still drawn by exactly the arithmetic of bnr_gig.
+    // nslot (host) = 2 x active waves: 4 (one wave per kind, two attempts per edge and round) or 8 (two waves per kind, four attempts).
     __shared__ double s_val[8][32];
     __shared__ int s_acc[8][32];
     int cap = 0;
-    if (2 * wave >= nslot) return;
-    const int el32 = lane & 31, slot = wave * 2 + (lane >> 5);
+    // nslot = 2 (throughput-bound launches: a lockstep group, large q): wave 0 alone draws, both kinds, two attempts per edge and round -- a second drawing
+    // wave per block costs such a launch more than the shorter chain saves (8 chains: 391 vs 385 us per sweep; one chain: 180.0 vs 181.9 with the split)
+    const bool split = nslot >= 4;
+    const int nw = split ? nslot >> 1 : 1;                 // active waves
+    const int nsk = split ? nw : 2;                        // attempt slots per edge and round: (nw / 2 waves of the edge's kind) x 2 half-waves
+    if (wave >= nw) return;
+    const int mykind = wave < (nw >> 1) ? 2 : 3, kw = split ? wave - (mykind == 3 ? (nw >> 1) : 0) : 0;
+    const int el32 = lane & 31, slot = kw * 2 + (lane >> 5);
     const int e = e0 + el32;
-    const bool act = el32 < ne;
+    const bool act = el32 < ne, keeper = wave == 0 && lane < 32;   // keeper: the lane that stores the edge's results and carries them into the sums
     double gam = 0.0, Snew = 1.0, W = 0.0;
     if (act) {
         W = cd.Wbuf[e];
         if (flags & 1) {
             double Sp = prev[cd.o_S + e];
             gam = tau * (cd.sz[e] + Sp * sdot[el32]) + W;
-            if (slot == 0) row[cd.o_gamma + e] = gam;
+            if (keeper) row[cd.o_gamma + e] = gam;
         } else gam = row[cd.o_gamma + e];
     }
     if (flags & 2) {
         const double g = gam - W, chi = (g * g) / tau2, psi = prev[ROW_THETA];
+        const int kind = act ? bnr_gig_kind(0.5, chi, psi) : 4;
+        const bool loop = kind == 2 || kind == 3, mine = split ? kind == mykind : loop;
         bnr_gig_ctx gc;
         gc.kind = 4;
-        if (act) bnr_gig_setup(gc, 0.5, chi, psi);
-        const bool loop = act && (gc.kind == 2 || gc.kind == 3);
+        if (mine || (keeper && act && !loop)) bnr_gig_setup(gc, 0.5, chi, psi);
         bool done = !loop;
-        for (uint32_t base = 0; base < BNR_MAX_ATTEMPTS; base += (uint32_t)nslot) {
+        for (uint32_t base = 0; base < BNR_MAX_ATTEMPTS; base += (uint32_t)nsk) {
             double v = 0.0;
-            const bool ok = !done && bnr_gig_try(gc, cd.seed, P.it, (uint32_t)e, base + (uint32_t)slot, v);
-            s_acc[slot][el32] = ok ? 1 : 0;
-            s_val[slot][el32] = v;
+            const bool ok = mine && !done && bnr_gig_try(gc, cd.seed, P.it, (uint32_t)e, base + (uint32_t)slot, v);
+            if (mine) { s_acc[slot][el32] = ok ? 1 : 0; s_val[slot][el32] = v; }       // (an edge's slots are written by the waves of its kind only)
             __syncthreads();
             if (!done) {
 #pragma unroll
-                for (int a = 7; a >= 0; --a) if (a < nslot && s_acc[a][el32]) { Snew = s_val[a][el32]; done = true; }   // lowest accepted attempt wins
+                for (int a = 7; a >= 0; --a) if (a < nsk && s_acc[a][el32]) { Snew = s_val[a][el32]; done = true; }   // lowest accepted attempt wins
             }
             if (!__syncthreads_or(done ? 0 : 1)) break;
         }
-        if (!done) { cap = 1; Snew = gc.alpha * gc.xm; }                      // attempt cap, as bnr_gig
-        if (act && !loop) Snew = bnr_gig_degenerate(gc, cd.seed, chi, psi, P.it, (uint32_t)e, &cap);
-        if (act && slot == 0) row[cd.o_S + e] = Snew;
+        if (__syncthreads_or(done ? 0 : 1)) {                                       // attempt cap, as bnr_gig: the fallback value comes from the wave that holds the setup
+            if (mine && !done && slot == 0) s_val[0][el32] = gc.alpha * gc.xm;
+            __syncthreads();
+            if (!done) { cap = 1; Snew = s_val[0][el32]; }
+        }
+        if (keeper && act && !loop) Snew = bnr_gig_degenerate(gc, cd.seed, chi, psi, P.it, (uint32_t)e, &cap);
+        if (keeper && act) row[cd.o_S + e] = Snew;
     } else if (act) Snew = row[cd.o_S + e];
     if (wave != 0) return;
     BNR_BSTAMP(2);

@@ -188,6 +188,19 @@ BNR_HD void bnr_gig_setup(bnr_gig_ctx &c, double lambda, double chi, double psi)
     }
     c.kind = 4;
 }
+// which of bnr_gig_setup's branches a draw takes (the same tests on the same expressions), without the setup's arithmetic
+BNR_HD int bnr_gig_kind(double lambda, double chi, double psi)
+{
+    const double eps10 = 2.220446049250313e-16 * 10.0;
+    if (chi < eps10) return 0;
+    if (psi < eps10) return 1;
+    if (lambda < 0.0) lambda = -lambda;
+    const double omega = sqrt(psi * chi);
+    const bool shift = (lambda > 2.0 || omega > 3.0);
+    if (shift || lambda >= 1.0 - 2.25 * (omega * omega) || omega > 0.2) return 2;
+    if (lambda >= 0.0 && omega > 0.0) return 3;
+    return 4;
+}
 // attempt k of a kind 2 / 3 draw: true and the value (already scaled by alpha) when accepted
 BNR_HD bool bnr_gig_try(const bnr_gig_ctx &c, uint64_t seed, uint32_t it, uint32_t elem, uint32_t k, double &out)
 {
