@@ -1907,13 +1907,22 @@ __global__ __launch_bounds__(256) void k_rhs(const SRC chain_src, int s)
     const int il = threadIdx.x & 63, g = threadIdx.x >> 6, i = blockIdx.x * 64 + il;
     double xw = 0.0, xs = 0.0;
     const int nb = cd.nblk_x;
+    // (the partials of a row are added in ascending block order whatever the batch size: 16 + 16 loads in flight per round trip instead of 8 + 8 -- the kernel is
+    // a chain of dependent round trips at the end of the scalar branch, which for a chain alone ends AFTER the factorization)
     int b = g;
-    for (; b + 28 < nb; b += 32) {
-        double w[8], a[8];
+    for (; b + 60 < nb; b += 64) {
+        double w[16], a[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { w[u] = cd.PW[(size_t)(b + 4 * u) * ld + i]; a[u] = cd.PA[(size_t)(b + 4 * u) * ld + i]; }
+        for (int u = 0; u < 16; ++u) { w[u] = cd.PW[(size_t)(b + 4 * u) * ld + i]; a[u] = cd.PA[(size_t)(b + 4 * u) * ld + i]; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { xw += w[u]; xs += a[u]; }
+        for (int u = 0; u < 16; ++u) { xw += w[u]; xs += a[u]; }
+    }
+    for (; b + 12 < nb; b += 16) {
+        double w[4], a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { w[u] = cd.PW[(size_t)(b + 4 * u) * ld + i]; a[u] = cd.PA[(size_t)(b + 4 * u) * ld + i]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { xw += w[u]; xs += a[u]; }
     }
     for (; b < nb; b += 4) { xw += cd.PW[(size_t)b * ld + i]; xs += cd.PA[(size_t)b * ld + i]; }
     sw[g][il] = xw; sa[g][il] = xs;
