@@ -829,7 +829,13 @@ static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
             // free (at most 4: they must stay shorter than a panel sweep; only while E is L2-sized -- for large n the update is
             // bandwidth-bound and wants every workgroup in flight at once: n=2000 408 vs 421 it/s)
             const int freecu = ncu - x.nb * npan;
-            const int spw = (freecu > 0 && nbk <= 24) ? std::min(x.spw_cap, std::max(1, (x.nb * nsup + freecu - 1) / freecu)) : 1;
+            // ... except at the first steps behind launch 0 (p <= 4): there every super block gets a workgroup of its own even where that puts update workgroups on
+            // CUs that hold a panel workgroup -- launch 0 has just streamed the Gram's partial tiles through the L2s, the blocks of E come from further away, and
+            // three of them in sequence per workgroup made these launches end on their update workgroups (in-kernel stamps, 8 chains: last update workgroup ends
+            // 11.0 / 10.7 / 7.3 / 7.5 us after the launch's start at p = 1..4 against 5.4-6.2 for the panel workgroups; with one block each 4.7 / 5.8 -- per sweep
+            // 385.9 -> 382.4 us in bench.py, 385.1 -> 376.6 in tools/ab_opt.py; one block each at EVERY step is slower again: 380.6 there)
+            const int cap = p <= 4 ? 1 : x.spw_cap;
+            const int spw = (freecu > 0 && nbk <= 24) ? std::min(cap, std::max(1, (x.nb * nsup + freecu - 1) / freecu)) : 1;
             if (few_ok && p >= 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_step<bnr_few>), dim3(x.nb, npan + (nsup + spw - 1) / spw), dim3(256), 0, st, few, p, s, 0, spw, fuse0);
             else BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + (nsup + spw - 1) / spw), dim3(256), 0, st, x, p, s, 0, spw, fuse0);
         } else {
