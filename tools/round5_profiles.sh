@@ -52,6 +52,7 @@ python bench.py --config cfg3 --chains-per-gpu 16 --steps 400 --warmup 40 --no-c
 for cfg in cfg4 cfg5; do
   python bench.py --config $cfg --chains-per-gpu 1 --steps 200 --warmup 16 --no-cpu-baseline --binary-x 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$cfg 1 chain, BINARY X (i8 Gram):', round(d['value'],1), 'it/s', round(d['ms_per_step']*1e3,1), 'us/sweep; digits + Gram', round(r['avg_launch_us'],1), 'us')" | tee -a $O/configs.txt
 done
+[ -n "$BNR_SKIP_PMC" ] && { echo "(PMC passes skipped)" | tee -a $O/progress.log; exit 0; }
 echo "== 4. PMC passes of the Gram kernels" | tee -a $O/progress.log
 cd /tmp
 cat > /tmp/tg5.py <<PY
