@@ -149,7 +149,7 @@ static int ensure_lds_attributes(int device)
     const int big = 124 * 1024;
     const void *fns[] = {(const void *)&k_tail<bnr_one>, (const void *)&k_tail<bnr_many>, (const void *)&k_backproj<bnr_one>,
                          (const void *)&k_backproj<bnr_many>, (const void *)&k_solve_a4<bnr_one>, (const void *)&k_solve_a4<bnr_many>,
-                         (const void *)&k_xpass_group};
+                         (const void *)&k_xpass_group, (const void *)&k_node<bnr_one>, (const void *)&k_node<bnr_many>};   // (k_node: 66.5 KB at R = 32)
     for (const void *f : fns) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     done[device] = 1;
     return BNR_OK;
@@ -659,7 +659,7 @@ static int check_launch(const char *what)
     } while (0)
 
 static void launch_node(bnr_exec &x, int s, int mode)
-{ BNR_LAUNCH(k_node, dim3(x.shape->V, 1, x.nb), dim3(64), 64 * (2 * x.shape->R + 1) * sizeof(double), x.stream, x, s, mode); }
+{ BNR_LAUNCH(k_node, dim3(x.shape->V, 1, x.nb), dim3(64), (size_t)(64 * (2 * x.shape->R + 1) + 4 * x.shape->R * x.shape->R + 2 * x.shape->R) * sizeof(double), x.stream, x, s, mode); }
 // the members of a lockstep group read the same device copy of X (chains of one fit made with bnr_chain_create_like)
 static bool group_shares_x(const bnr_exec &x)
 {

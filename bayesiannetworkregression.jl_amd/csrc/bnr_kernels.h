@@ -273,10 +273,11 @@ template <class SRC>
 __global__ __launch_bounds__(64) void k_node(const SRC chain_src, int s, int mode)
 {
     const bnr_dev &cd = chain_src.get();
-    extern __shared__ double shn[];                           // 64 x (2R + 1): per staged node [U(R) | V(R) | g/h]
-    __shared__ double sM[BNR_RMAX * BNR_RMAX], sMinv[BNR_RMAX * BNR_RMAX], sS[BNR_RMAX * BNR_RMAX], sL[BNR_RMAX * BNR_RMAX];
-    __shared__ double slam[BNR_RMAX], sc[BNR_RMAX];
+    extern __shared__ double shn[];                           // 64 x (2R + 1): per staged node [U(R) | V(R) | g/h], then the R x R work matrices
     const int lane = threadIdx.x, k = blockIdx.x, V = cd.V, R = cd.R;
+    // (sized by the fit's R, not by BNR_RMAX: 800 of these one-wave workgroups run beside the panel steps of the factorization, and with 33 KB of static LDS
+    // each they took the room that the next step's workgroups needed on the CU)
+    double *sM = shn + 64 * (2 * R + 1), *sMinv = sM + R * R, *sS = sMinv + R * R, *sL = sS + R * R, *slam = sL + R * R, *sc = slam + R;
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     double *row = cd.trace + (size_t)P.row * cd.rowlen;
     const double *prev = cd.trace + (size_t)P.prev * cd.rowlen;
