@@ -2095,11 +2095,13 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
     const bool split = nslot >= 4;
     const int nw = split ? nslot >> 1 : 1;                 // active waves
     const int nsk = split ? nw : 2;                        // attempt slots per edge and round: (nw / 2 waves of the edge's kind) x 2 half-waves
-    if (wave >= nw) return;
+    // the wave that draws alone (and keeps the results) rotates with the block: the drawing waves of the blocks that share a CU then sit on different SIMDs
+    const int dw = split ? 0 : (bid & 3);
+    if (split ? wave >= nw : wave != dw) return;
     const int mykind = wave < (nw >> 1) ? 2 : 3, kw = split ? wave - (mykind == 3 ? (nw >> 1) : 0) : 0;
     const int el32 = lane & 31, slot = kw * 2 + (lane >> 5);
     const int e = e0 + el32;
-    const bool act = el32 < ne, keeper = wave == 0 && lane < 32;   // keeper: the lane that stores the edge's results and carries them into the sums
+    const bool act = el32 < ne, keeper = wave == dw && lane < 32;   // keeper: the lane that stores the edge's results and carries them into the sums
     double gam = 0.0, Snew = 1.0, W = 0.0;
     if (act) {
         W = cd.Wbuf[e];
@@ -2121,22 +2123,25 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
             double v = 0.0;
             const bool ok = mine && !done && bnr_gig_try(gc, cd.seed, P.it, (uint32_t)e, base + (uint32_t)slot, v);
             if (mine) { s_acc[slot][el32] = ok ? 1 : 0; s_val[slot][el32] = v; }       // (an edge's slots are written by the waves of its kind only)
-            __syncthreads();
+            // (one drawing wave: its two half-waves meet through LDS with wave-level synchronisation only -- the other waves of the block have left, and a block-wide
+            // vote must not be asked of a block whose wave 0 is gone)
+            if (split) __syncthreads(); else bnr_wsync();
             if (!done) {
 #pragma unroll
                 for (int a = 7; a >= 0; --a) if (a < nsk && s_acc[a][el32]) { Snew = s_val[a][el32]; done = true; }   // lowest accepted attempt wins
             }
-            if (!__syncthreads_or(done ? 0 : 1)) break;
+            if (split) { if (!__syncthreads_or(done ? 0 : 1)) break; }
+            else { bnr_wsync(); if (__ballot(!done) == 0ull) break; }
         }
-        if (__syncthreads_or(done ? 0 : 1)) {                                       // attempt cap, as bnr_gig: the fallback value comes from the wave that holds the setup
+        if (split ? __syncthreads_or(done ? 0 : 1) != 0 : __ballot(!done) != 0ull) {   // attempt cap, as bnr_gig: the fallback value comes from the wave that holds the setup
             if (mine && !done && slot == 0) s_val[0][el32] = gc.alpha * gc.xm;
-            __syncthreads();
+            if (split) __syncthreads(); else bnr_wsync();
             if (!done) { cap = 1; Snew = s_val[0][el32]; }
         }
         if (keeper && act && !loop) Snew = bnr_gig_degenerate(gc, cd.seed, chi, psi, P.it, (uint32_t)e, &cap);
         if (keeper && act) row[cd.o_S + e] = Snew;
     } else if (act) Snew = row[cd.o_S + e];
-    if (wave != 0) return;
+    if (wave != dw) return;
     BNR_BSTAMP(2);
     if (!(flags & 4)) { if (cap && lane < 32) atomicAdd((unsigned long long *)&cd.counters[2], 1ull); return; }
     double *ps = cd.Psum + (size_t)bid * (1 + 3 * R);
