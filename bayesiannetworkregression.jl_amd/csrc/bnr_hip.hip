@@ -266,7 +266,6 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
         return fail(BNR_ERR_BAD_ARG, "need n>=1, V>=2, 1<=R<=32, tot_save>=2");
     // LDS budgets of the kernels that stage a whole vector / the R x V matrix u: k_tail keeps u (R V doubles) next to 33 KiB of
     // static arrays, k_backproj / k_solve_a4 keep an n-vector; 160 KiB per workgroup on gfx950
-    if ((size_t)R * V > 15360) return fail(BNR_ERR_BAD_ARG, "R*V must not exceed 15360 (u is staged in LDS by the scalar tail kernel)");
     if (n > 14000) return fail(BNR_ERR_BAD_ARG, "n must not exceed 14000 (n-vectors are staged in LDS)");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
@@ -857,7 +856,7 @@ static void launch_backproj(bnr_exec &x, int s, int flags)
     BNR_LAUNCH(k_backproj, dim3(round_up(x.shape->nblk_bp, 8) * x.nb), dim3(256), lds, x.stream, x, s, flags | wide, x.nb, nslot);
 }
 static void launch_tail(bnr_exec &x, int s, int mask, int xg_src)
-{ BNR_LAUNCH(k_tail, dim3(1, 1, x.nb), dim3(BNR_TAIL_THREADS), (size_t)x.shape->R * x.shape->V * sizeof(double), x.stream, x, s, mask, xg_src); }
+{ BNR_LAUNCH(k_tail, dim3(1, 1, x.nb), dim3(BNR_TAIL_THREADS), (size_t)x.shape->R * x.shape->V <= BNR_TAIL_U_LDS ? (size_t)x.shape->R * x.shape->V * sizeof(double) : 0, x.stream, x, s, mask, xg_src); }
 // The scalar tail of sweep s with everything it needs: with split_sums the per-block partial sums of update_theta! / update_Lambda!
 // (gibbs.jl:476, 603-605) are not computed by the back-projection on the critical chain but by a launch of their own in front of the tail --
 // the same kernel with flags = 4, the same sums in the same order.

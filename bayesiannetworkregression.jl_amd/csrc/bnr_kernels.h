@@ -2221,6 +2221,7 @@ __device__ inline void wave_tri_inverse(const double *A, double *T, int R, int l
     bnr_wsync();
 }
 
+#define BNR_TAIL_U_LDS 15360     // doubles of u (R x V) that k_tail stages in LDS (120 KB); a larger u is read from the trace row (same values, same order of operations)
 #define BNR_TAIL_THREADS 512   // 8 wavefronts: the seven role waves of phase 3 + one; two per SIMD, so the kernel may use 256 vector registers (no spills: with
                                // 1024 threads it had 128 and spilled) and fits a CU beside other resident workgroups instead of needing an empty one.
                                // NOT a tunable: the block-wide reductions of k_tail (sum of squared residuals, sig_q, the mu / tau2 sums) stride by the thread
@@ -2231,7 +2232,7 @@ template <class SRC>
 __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, int s, int mask, int xg_src)
 {
     const bnr_dev &cd = chain_src.get();
-    extern __shared__ double su[];               // R x V: u of this row (staged once, used by Psi and by the q pass)
+    extern __shared__ double su_lds[];           // R x V: u of this row (staged once, used by Psi and by the q pass) -- where it fits the LDS budget (BNR_TAIL_U_LDS), else read from the row
     __shared__ double sred[3 * 16];
     __shared__ double sPsi[BNR_RMAX * BNR_RMAX], sA[BNR_RMAX * BNR_RMAX], sT[BNR_RMAX * BNR_RMAX], sBm[BNR_RMAX * BNR_RMAX];
     __shared__ double sll[3 * BNR_RMAX + 1], slam[BNR_RMAX], spi[3 * BNR_RMAX];
@@ -2255,7 +2256,9 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
     BNR_TSTAMP(0);
     if (tid < R) slam[tid] = row[cd.o_lam + tid];
     if (tid == 0) { sval[1] = row[ROW_MU]; sflag[0] = 0; sflag[1] = 0; }
-    for (int i = tid; i < R * V; i += blockDim.x) su[i] = row[cd.o_u + i];
+    const bool u_lds = R * V <= BNR_TAIL_U_LDS;
+    if (u_lds) for (int i = tid; i < R * V; i += blockDim.x) su_lds[i] = row[cd.o_u + i];
+    const double *su = u_lds ? (const double *)su_lds : (const double *)(row + cd.o_u);
 
     // ---- phase 1: reductions.  Psum partials (32 lanes per output, fixed order); X gamma from the PG partials
     if (mask & (1 | 16)) {

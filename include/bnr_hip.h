@@ -61,7 +61,8 @@ int bnr_runtime_version(int *version);               /* hipRuntimeGetVersion of 
 /* Allocate a chain: copies X (n x q col-major) and y to HBM, allocates the tot_save-row state table and all
  * work space on `device`.  Replaces the allocation half of initialize_and_run! (gibbs.jl:822-841).
  * The RNG stream is keyed by seed + chain_id (the reference's Xoshiro(seed+c), gibbs.jl:928).
- * Limits (BNR_ERR_BAD_ARG otherwise): 1 <= R <= 32, V >= 2, R*V <= 15360, n <= 14000 (LDS budgets of single-workgroup kernels). */
+ * Limits (BNR_ERR_BAD_ARG otherwise): 1 <= R <= 32, V >= 2, n <= 14000 (LDS budgets of single-workgroup kernels; round 5: R*V is no longer limited --
+ * beyond 15360 the scalar tail reads u from the table row instead of staging it in LDS). */
 int bnr_chain_create(int32_t n, int32_t V, int32_t R, const double *X, const double *y, const bnr_hyper *hyper,
                      uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save, bnr_chain **out);
 /* The same with the model matrix in the caller's own element type -- the reference builds X_new as Matrix{eltype(T)} (gibbs.jl:917:

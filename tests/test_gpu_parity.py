@@ -919,8 +919,8 @@ def test_random_shapes_and_hyperparameters_match_oracle(gpu):
 
 def test_shapes_at_the_lds_budgets(gpu):
     """u (R x V) and the n-vectors are staged in LDS by single workgroups: shapes that need more than the default 64 KiB of
-    dynamic LDS run (R V = 9600: 75 KiB in k_tail; R = 32 is the latent-dimension limit), shapes beyond the 160 KiB of the
-    CU are rejected at bnr_chain_create with a message instead of failing at a launch."""
+    dynamic LDS run (R V = 9600: 75 KiB in k_tail; R = 32 is the latent-dimension limit); n beyond the LDS of the CU is
+    rejected at bnr_chain_create with a message instead of failing at a launch; R V beyond it runs with u read from the row."""
     X, y, _ = bnr_amd.make_synthetic(20, 300, 32, seed=1)
     ch = bnr_amd.Chain(X, y, 32, 4, 1, 1, nu=34)                # the inverse Wishart needs nu >= R
     ch.init_prior()
@@ -930,9 +930,24 @@ def test_shapes_at_the_lds_budgets(gpu):
     c = ch.counters()
     assert c["chol_fail"] == 0 and c["nan_w"] == 0
     ch.close()
+    # R V beyond what k_tail can stage (15 360 doubles): u is read from the trace row instead -- the reference has no such limit (round 5; rounds 1-4 refused
+    # the shape).  R V = 19 200, q = 180 300: the prior draw and two sweeps against the oracle, alone and in a lockstep group
     Xb, yb, _ = bnr_amd.make_synthetic(5, 600, 32, seed=1)
-    with pytest.raises(bnr_amd.BnrError, match="R\\*V must not exceed"):
-        bnr_amd.Chain(Xb, yb, 32, 4, 1, 1, nu=34)
+    chb, ob = pair(Xb, yb, 32, 3, 1, nu=34)
+    mate = bnr_amd.Chain.like(chb, 1, 2, 3)
+    chb.init_prior(); mate.init_prior(); ob.init_prior()
+    g = bnr_amd.Group([chb, mate])
+    g.run(2, 3, 3)
+    ob.run(2, 3, 3)
+    assert_tables_close(chb.fetch(), ob.t, what="R V = 19200 (u from the row)")
+    solo = bnr_amd.Chain.like(chb, 1, 1, 3)
+    solo.init_prior()
+    solo.run(2, 3, 3)
+    tg, ts = chb.fetch(), solo.fetch()
+    assert all(np.array_equal(tg[k], ts[k]) for k in bo.COLUMNS)
+    g.close()
+    for c_ in (chb, mate, solo):
+        c_.close()
     with pytest.raises(bnr_amd.BnrError, match="n must not exceed"):
         bnr_amd.Chain(np.zeros((14001, 3), order="F"), np.zeros(14001), 2, 4, 1, 1)
 
