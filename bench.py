@@ -295,7 +295,7 @@ def main():
         X = bnr_amd.XInput(np.asfortranarray(np.random.default_rng(a.seed).random((n, q)) < 0.5), False)
     K, W = a.steps, a.warmup
     total_chains = world * a.chains_per_gpu if a.chains_per_gpu > 0 else a.chains
-    tot = W + K + min(K, 200) + 1
+    tot = W + K + max(100, min(K, 200)) + 1
     chains = []
     ids = [c for c in range(1, total_chains + 1) if (c - 1) % world == rank]  # round-robin over ranks, as api.local_chain_ids
     if not ids:
@@ -324,7 +324,9 @@ def main():
         if profile:
             runner.set_profiling(False)
 
-    P = min(K, 200)                                  # sweeps of the HIP-event pass around k_gram (after the timed region)
+    P = max(100, min(K, 200))                        # sweeps of the HIP-event pass around k_gram (after the timed region; at least 50 launches per schedule whatever --steps is:
+                                                     # with the driver's 20 steps the pass used to average 10 eager launches, the first of them behind a schedule switch -- 207 us against
+                                                     # the 190-191 us rocprofv3 reports over hundreds of launches of the same kernel)
 
     # capture + instantiate the hipGraphs here and replay them on scratch rows (discarded sweeps: the runtime's first-replay
     # setup and the clock ramp of an idle GPU stay out of the timed region whatever --warmup is); then the W warm-up steps
