@@ -368,7 +368,7 @@ def main():
     if C > 1 and world == 1:
         runner.close()
         runner = None
-        Ks = min(K, 1000)
+        Ks = min(max(K, 200), 1000)                   # (a sub-record with its own step count: at least 200 sweeps, so that the driver's short run reports the same one-chain rate as a long one)
         solo = bnr_amd.Chain.like(chains[0], a.seed, ids[0], Ks + 50)
         solo.init_prior()
         solo.run(2, 49, 49)
