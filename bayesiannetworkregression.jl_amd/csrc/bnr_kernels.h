@@ -2441,16 +2441,24 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
         if (wave != 0) {                          // wavefront 0 is busy with the matrix work above
             const int t = tid - 64, nt = blockDim.x - 64;
             for (int i = t; i < n; i += nt) { double rv = cd.y[i] - mu - cd.xg[i]; racc += rv * rv; }
-            if (u_lds)
-                for (int e = t; e < q; e += nt) {
-                    double g = row[cd.o_gamma + e] - edge_W(su_lds, slam, R, cd.el[e], cd.ek[e]);
-                    qacc += ((g * g) / 2.0) / row[cd.o_S + e];
-                }
-            else
-                for (int e = t; e < q; e += nt) {
-                    double g = row[cd.o_gamma + e] - edge_W(su_row, slam, R, cd.el[e], cd.ek[e]);
-                    qacc += ((g * g) / 2.0) / row[cd.o_S + e];
-                }
+            // four edges of a thread in flight per trip (their index / gamma / S loads are independent; one edge per trip was one round trip to memory per edge:
+            // 100 trips at q = 45 150 made this pass 100 of k_tail's 152 us there), the terms added in the same order as before
+#define BNR_TAIL_QPASS(SU)                                                                                                     \
+            {                                                                                                                  \
+                int e = t;                                                                                                     \
+                if (q >= 16 * nt)            /* (short passes keep the plain loop: at q = 5 050, 11 edges per thread, the blocked form was 0.7 us per sweep slower) */ \
+                for (; e + 3 * nt < q; e += 4 * nt) {                                                                          \
+                    int l4[4], k4[4]; double g4[4], s4[4];                                                                     \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) { const int ej = e + j * nt; l4[j] = cd.el[ej]; k4[j] = cd.ek[ej]; g4[j] = row[cd.o_gamma + ej]; s4[j] = row[cd.o_S + ej]; } \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) { const double g = g4[j] - edge_W(SU, slam, R, l4[j], k4[j]); qacc += ((g * g) / 2.0) / s4[j]; } \
+                }                                                                                                              \
+                for (; e < q; e += nt) {                                                                                       \
+                    double g = row[cd.o_gamma + e] - edge_W(SU, slam, R, cd.el[e], cd.ek[e]);                                  \
+                    qacc += ((g * g) / 2.0) / row[cd.o_S + e];                                                                 \
+                }                                                                                                              \
+            }
+            if (u_lds) BNR_TAIL_QPASS(su_lds)
+            else BNR_TAIL_QPASS(su_row)
         }
         racc = wave_sum(racc); qacc = wave_sum(qacc);
         __syncthreads();
