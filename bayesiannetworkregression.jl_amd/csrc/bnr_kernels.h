@@ -2021,6 +2021,9 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
 #define BNR_BSTAMP(slot) do { } while (0)
 #endif
     BNR_BSTAMP(0);
+#ifdef BNR_STAMPS
+    if (tid == 0 && bid < 1800) cd.dbg[400 + 2 * bid] = __builtin_amdgcn_s_memrealtime();
+#endif
     // u[r,l] u[r,k] of this block's edges for the Lambda log-likelihoods at the end: requested now, so that the dependent
     // global loads (edge -> nodes -> u) are in flight behind the dot products instead of in front of the final sums
     __shared__ double sdr[BNR_RMAX * 33];
@@ -2077,6 +2080,9 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
     }
     __syncthreads();
     BNR_BSTAMP(1);
+#ifdef BNR_STAMPS
+    if (tid == 0 && bid < 1000) cd.dbg[2000 + bid] = __builtin_amdgcn_s_memrealtime();
+#endif
     // update_D! (gibbs.jl:454-458): the rejection attempts of one GIG draw are independent given their counter, so several
     // attempts of every edge are evaluated side by side (half-wave = 32 edges x one attempt) and the first accepted one is
     // taken -- the same draw as the sequential loop of bnr_gig, in ~1 round instead of 3-5 dependent ones.  nslot (host) = 8
@@ -2171,6 +2177,9 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
         ps[j] = acc;
     }
     BNR_BSTAMP(3);
+#ifdef BNR_STAMPS
+    if (lane == 0 && bid < 1800) cd.dbg[401 + 2 * bid] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (cap && lane < 32) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
 }
 
