@@ -149,7 +149,7 @@ static int ensure_lds_attributes(int device)
     const int big = 124 * 1024;
     const void *fns[] = {(const void *)&k_tail<bnr_one>, (const void *)&k_tail<bnr_many>, (const void *)&k_backproj<bnr_one>,
                          (const void *)&k_backproj<bnr_many>, (const void *)&k_solve_a4<bnr_one>, (const void *)&k_solve_a4<bnr_many>,
-                         (const void *)&k_xpass_group, (const void *)&k_node<bnr_one>, (const void *)&k_node<bnr_many>};   // (k_node: 66.5 KB at R = 32)
+                         (const void *)&k_xpass_group, (const void *)&k_xpass_group2, (const void *)&k_node<bnr_one>, (const void *)&k_node<bnr_many>};   // (k_node: 66.5 KB at R = 32)
     for (const void *f : fns) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     done[device] = 1;
     return BNR_OK;
@@ -674,7 +674,10 @@ static void launch_xpass(bnr_exec &x, int s, int which)
     const bool big_x = (size_t)x.shape->n_pad * x.shape->q * sizeof(double) >= ((size_t)8 << 20);
     if (which == 3 && (x.group_xpass == 1 || (x.group_xpass < 0 && big_x)) && group_shares_x(x) && 16 * (size_t)x.shape->chunk_x * sizeof(double) <= 48 * 1024) {
         // one workgroup per column chunk and row slice for all members: X comes out of the L2s once, not once per chain
-        hipLaunchKernelGGL(k_xpass_group, dim3(x.shape->nblk_x * ((x.shape->n_pad + 255) / 256)), dim3(256), 16 * x.shape->chunk_x * sizeof(double), x.stream, bnr_many{x.cds}, s, x.nb);
+        // long column chunks (large q: 177 columns per workgroup at config 5): the straight-line column loop -- config 5 x 8 chains, where the scalar branch is the longer
+        // chain behind the Gram; at the headline shape (32 columns per workgroup) it brought nothing per sweep (notes S), so short chunks keep the first kernel
+        if (x.shape->chunk_x > 64) hipLaunchKernelGGL(k_xpass_group2, dim3(x.shape->nblk_x * ((x.shape->n_pad + 255) / 256)), dim3(256), 16 * x.shape->chunk_x * sizeof(double), x.stream, bnr_many{x.cds}, s, x.nb);
+        else hipLaunchKernelGGL(k_xpass_group, dim3(x.shape->nblk_x * ((x.shape->n_pad + 255) / 256)), dim3(256), 16 * x.shape->chunk_x * sizeof(double), x.stream, bnr_many{x.cds}, s, x.nb);
         return;
     }
     BNR_LAUNCH(k_xpass, dim3(round_up(x.shape->nblk_x, 8) * x.nb), dim3(256), 3 * x.shape->chunk_x * sizeof(double), x.stream, x, s, which, x.nb);

@@ -555,6 +555,90 @@ __global__ __launch_bounds__(256) void k_xpass_group(const bnr_many chain_src, i
     }
 }
 
+// k_xpass_group2: k_xpass_group for long column chunks (chunk_x > 64: large q).  The column loop for NC members, straight-line: 16 columns of X in flight, the 2 NC multipliers of a column (W and sqrt(S) z1 of every member) contiguous
+// in LDS (sWZ[column][member][2]: four 16-byte reads per column for eight members).  Round 5: the earlier form -- run-time member count tested inside the unrolled loops, one
+// 8-byte LDS read per multiply-add -- waited for LDS in front of every multiply-add: 15.8 us of the kernel's 21 (in-kernel stamps, alone on the chip) for 2 x 16 columns.
+typedef double bnr_d2 __attribute__((ext_vector_type(2)));
+template <int NC, class XT>
+__device__ __forceinline__ void bnr_xg_columns(const XT *xp, size_t ld, int ne, const double *sWZ, double (&aw)[8], double (&aa)[8])
+{
+    int t0 = 0;
+    for (; t0 + 16 <= ne; t0 += 16) {
+        XT xv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) xv[u] = xp[(size_t)(t0 + u) * ld];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const double x = (double)xv[u];
+            const bnr_d2 *o = (const bnr_d2 *)(sWZ + (size_t)(t0 + u) * 16);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { const bnr_d2 wz = o[c]; aw[c] = fma(x, wz[0], aw[c]); aa[c] = fma(x, wz[1], aa[c]); }
+        }
+    }
+    for (; t0 < ne; ++t0) {
+        const double x = (double)xp[(size_t)t0 * ld];
+        const bnr_d2 *o = (const bnr_d2 *)(sWZ + (size_t)t0 * 16);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { const bnr_d2 wz = o[c]; aw[c] = fma(x, wz[0], aw[c]); aa[c] = fma(x, wz[1], aa[c]); }
+    }
+}
+template <class XT>
+__device__ __forceinline__ void bnr_xg_dispatch(int nc, const XT *xp, size_t ld, int ne, const double *sWZ, double (&aw)[8], double (&aa)[8])
+{
+    switch (nc) {
+    case 1: bnr_xg_columns<1>(xp, ld, ne, sWZ, aw, aa); break;
+    case 2: bnr_xg_columns<2>(xp, ld, ne, sWZ, aw, aa); break;
+    case 3: bnr_xg_columns<3>(xp, ld, ne, sWZ, aw, aa); break;
+    case 4: bnr_xg_columns<4>(xp, ld, ne, sWZ, aw, aa); break;
+    case 5: bnr_xg_columns<5>(xp, ld, ne, sWZ, aw, aa); break;
+    case 6: bnr_xg_columns<6>(xp, ld, ne, sWZ, aw, aa); break;
+    case 7: bnr_xg_columns<7>(xp, ld, ne, sWZ, aw, aa); break;
+    default: bnr_xg_columns<8>(xp, ld, ne, sWZ, aw, aa); break;
+    }
+}
+__global__ __launch_bounds__(256) void k_xpass_group2(const bnr_many chain_src, int s, int nchains)
+{
+    if (BNR_EXP_SKIP_SCALAR()) return;
+    const bnr_dev &c0 = chain_src.at(0);                  // the geometry and the shared X, index maps
+    const int rs = (c0.n_pad + 255) / 256, bid = blockIdx.x / rs, slice = blockIdx.x % rs, tid = threadIdx.x;
+    const int chunk = c0.chunk_x, e0 = bid * chunk, ne = min(chunk, c0.q - e0), R = c0.R;
+    const size_t ld = c0.n_pad;
+    extern __shared__ double sh[];
+    double *sWZ = sh;                                      // [column of the chunk][member][W, sqrt(S) z1]
+    __shared__ double *s_pw[8], *s_pa[8];
+    const int i = slice * 256 + tid;
+    const bool live = i < c0.n_pad;                        // n_pad is a multiple of 64: the last slice may be short
+    const int ic = live ? i : 0;
+    for (int cb = 0; cb < nchains; cb += 8) {
+        const int nc = min(8, nchains - cb);
+        __syncthreads();
+        for (int it = tid; it < nc * chunk; it += 256) {
+            const int c = it / chunk, t = it - c * chunk;
+            const bnr_dev &cd = chain_src.at(cb + c);
+            const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
+            const double *row = cd.trace + (size_t)P.row * cd.rowlen, *prev = cd.trace + (size_t)P.prev * cd.rowlen;
+            double w = 0.0, zz = 0.0;
+            if (t < ne) {
+                const int e = e0 + t;
+                w = edge_W(row + cd.o_u, prev + cd.o_lam, R, cd.el[e], cd.ek[e]);
+                zz = sqrt(prev[cd.o_S + e]) * bnr_normal(cd.seed, P.it, SITE_G_Z1, (uint32_t)e, 0);
+                if (slice == 0) { cd.Wbuf[e] = w; cd.sz[e] = zz; }
+            }
+            sWZ[(size_t)t * 16 + 2 * c] = w; sWZ[(size_t)t * 16 + 2 * c + 1] = zz;
+        }
+        if (tid < nc) { const bnr_dev &cd = chain_src.at(cb + tid); s_pw[tid] = cd.PW; s_pa[tid] = cd.PA; }
+        __syncthreads();
+        double aw[8], aa[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { aw[c] = 0.0; aa[c] = 0.0; }
+        if (c0.X8) bnr_xg_dispatch(nc, c0.X8 + (size_t)e0 * ld + ic, ld, ne, sWZ, aw, aa);
+        else bnr_xg_dispatch(nc, c0.X + (size_t)e0 * ld + ic, ld, ne, sWZ, aw, aa);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < nc && live) { s_pw[c][(size_t)bid * ld + i] = aw[c]; s_pa[c][(size_t)bid * ld + i] = aa[c]; }
+    }
+}
+
 // ===================================================================================== k_gram
 // G = X diag(S_prev) X'  (the n x n matrix of gibbs.jl:434 without the identity; tau cancels: Xt tau2 D Xt' = X D X').
 // v_mfma_f64_16x16x4_f64, D = A*B + C with A[m][k] (lane l: m = l&15, k = l>>4), B[k][n] (k = l>>4, n = l&15),

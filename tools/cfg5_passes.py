@@ -18,7 +18,7 @@ chains += [bnr_amd.Chain.like(chains[0], 21, c, tot) for c in range(2, C + 1)]
 for ch in chains:
     if kind != "real":
         ch.set_option("byte_x", 1 if kind == "bool8" else 0)
-        ch.set_option("gram_i8", 0)
+        pass
     ch.init_prior()
 runner = bnr_amd.Group(chains) if C > 1 else chains[0]
 if pair:                                   # 1 = k_backproj2, 2 = k_backproj3: only in a build with tools/experiments/backproj_pipelines.patch applied
