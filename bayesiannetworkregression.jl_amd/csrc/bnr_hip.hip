@@ -728,14 +728,16 @@ static bool gram_on_i8(const bnr_exec &x)
         if (!x.cds_pin[i].XM) return false;
     return true;
 }
+// workgroups per chain of k_sdigits: one per 2048 entries of the digit planes, at most 32 (each finds the largest S itself, then converts its slice)
+static unsigned sdig_slices(const bnr_dev &d) { return (unsigned)std::max(1, std::min(32, (d.kslab + 2047) / 2048)); }
 #define BNR_LAUNCH_I8(LL)                                                                                                                   \
     do {                                                                                                                                    \
         const size_t lds = bnr_i8_lds_bytes(LL, d.kcp);                                                                                     \
         if (x.nb == 1) {                                                                                                                    \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sdigits<bnr_one, LL>), dim3(1), dim3(1024), 0, st, bnr_one{d}, s);                          \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sdigits<bnr_one, LL>), dim3(1, sdig_slices(d)), dim3(1024), 0, st, bnr_one{d}, s);                          \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram_i8<bnr_one, LL>), ggrid, dim3(256), lds, st, bnr_one{d}, s, 1);                        \
         } else {                                                                                                                            \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sdigits<bnr_many, LL>), dim3(x.nb), dim3(1024), 0, st, bnr_many{x.cds}, s);                 \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sdigits<bnr_many, LL>), dim3(x.nb, sdig_slices(d)), dim3(1024), 0, st, bnr_many{x.cds}, s);                 \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gram_i8<bnr_many, LL>), ggrid, dim3(256), lds, st, bnr_many{x.cds}, s, x.nb);               \
         }                                                                                                                                   \
     } while (0)

@@ -1069,13 +1069,18 @@ __global__ void k_x_mask(const unsigned char *X8, int n, int n_pad, int q, int k
 template <class SRC, int L>
 __global__ __launch_bounds__(1024) void k_sdigits(const SRC chain_src, int s)
 {
-    const bnr_dev &cd = chain_src.get_x();                    // grid = (chains)
+    const bnr_dev &cd = chain_src.get_x();                    // grid = (chains, slices): every workgroup finds the largest S itself (q values out of the L2: the maximum does
+                                                              // not depend on who computes it) and converts its slice of the entries -- one workgroup per chain took 38 us at
+                                                              // q = 45 150 on the critical chain in front of the i8 Gram (round 5, third session)
     const int tid = threadIdx.x;
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     const double *S = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
     __shared__ double red[16];
-    double m = 0.0;
-    for (int k = tid; k < cd.q; k += 1024) m = fmax(m, S[k]);
+    double m = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+    int k = tid;
+    for (; k + 3072 < cd.q; k += 4096) { m = fmax(m, S[k]); m1 = fmax(m1, S[k + 1024]); m2 = fmax(m2, S[k + 2048]); m3 = fmax(m3, S[k + 3072]); }
+    for (; k < cd.q; k += 1024) m = fmax(m, S[k]);
+    m = fmax(fmax(m, m1), fmax(m2, m3));
     m = fmax(m, __shfl_xor(m, 32)); m = fmax(m, __shfl_xor(m, 16)); m = fmax(m, __shfl_xor(m, 8));
     m = fmax(m, __shfl_xor(m, 4)); m = fmax(m, __shfl_xor(m, 2)); m = fmax(m, __shfl_xor(m, 1));
     if ((tid & 63) == 0) red[tid >> 6] = m;
@@ -1086,9 +1091,9 @@ __global__ __launch_bounds__(1024) void k_sdigits(const SRC chain_src, int s)
     (void)frexp(m, &e);                                       // m = f 2^e with f in [0.5, 1): every S_k < 2^e
     constexpr int BITS = 8 * L - 2;                           // S_k up < 2^BITS <= 2^62: the top digit stays below 64, a carry cannot overflow it
     const double up = ldexp(1.0, BITS - e);
-    if (tid == 0) cd.scal[SC_I8SCALE] = ldexp(1.0, e - BITS);
+    if (tid == 0 && blockIdx.y == 0) cd.scal[SC_I8SCALE] = ldexp(1.0, e - BITS);
     const int kchunk = cd.q_pad / cd.ksplit;
-    for (int idx = tid; idx < cd.kslab; idx += 1024) {
+    for (int idx = (int)blockIdx.y * 1024 + tid; idx < cd.kslab; idx += (int)gridDim.y * 1024) {
         const int ks = idx / cd.kcp, kk = idx % cd.kcp, k = ks * kchunk + kk;
         unsigned long long N = 0;
         if (kk < kchunk && k < cd.q) N = (unsigned long long)(S[k] * up);
