@@ -66,6 +66,7 @@ struct bnr_exec {
     unsigned long long *lflags = nullptr;               // the counters the streams meet through
     struct lrung { int k, part, which; hipGraph_t graph; hipGraphExec_t gexec; };
     std::vector<lrung> lladder;
+    int wide_backproj = -1;                              // 1: k_backproj64 (64 edges per workgroup, one edge per lane of the drawing wave); -1: launches of many rounds (a group at large q)
     int split_sums = -1;                                 // 1: the back-projection's partial sums as a launch of their own in front of the scalar tail (off the critical chain)
     int spw_cap = 4;                                    // super blocks per update workgroup of the factorization, at most
     int factor_variant = -1;                            // -1: chosen by size; 0: right-looking k_chol_step (+ k_gram_reduce); 1: left-looking k_chol_ll
@@ -149,7 +150,7 @@ static int ensure_lds_attributes(int device)
     const int big = 124 * 1024;
     const void *fns[] = {(const void *)&k_tail<bnr_one>, (const void *)&k_tail<bnr_many>, (const void *)&k_backproj<bnr_one>,
                          (const void *)&k_backproj<bnr_many>, (const void *)&k_solve_a4<bnr_one>, (const void *)&k_solve_a4<bnr_many>,
-                         (const void *)&k_xpass_group, (const void *)&k_xpass_group2, (const void *)&k_node<bnr_one>, (const void *)&k_node<bnr_many>};   // (k_node: 66.5 KB at R = 32)
+                         (const void *)&k_xpass_group, (const void *)&k_xpass_group2, (const void *)&k_backproj64<bnr_one>, (const void *)&k_backproj64<bnr_many>, (const void *)&k_node<bnr_one>, (const void *)&k_node<bnr_many>};   // (k_node: 66.5 KB at R = 32)
     for (const void *f : fns) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     done[device] = 1;
     return BNR_OK;
@@ -855,6 +856,15 @@ static void launch_solve(bnr_exec &x)
 }
 static void launch_backproj(bnr_exec &x, int s, int flags)
 {
+    {
+        // many rounds of workgroups (a lockstep group at large q): only the instructions per edge count -- one edge per lane of the drawing wave (k_backproj64)
+        const size_t lds64 = ((size_t)x.shape->n_pad + 64 + (size_t)x.shape->R * 65 + (size_t)(3 * x.shape->R + 1) * 65) * sizeof(double);
+        const bool many_rounds = (size_t)x.nb * x.shape->nblk_bp >= (size_t)12 * x.ncu;
+        if ((flags & 3) == 3 && lds64 <= 124 * 1024 && (x.wide_backproj == 1 || (x.wide_backproj < 0 && many_rounds))) {
+            BNR_LAUNCH(k_backproj64, dim3(round_up((x.shape->nblk_bp + 1) / 2, 8) * x.nb), dim3(256), lds64, x.stream, x, s, flags, x.nb);
+            return;
+        }
+    }
     size_t lds = std::max<size_t>(x.shape->n_pad + 64, (size_t)(3 * x.shape->R + 1) * 33) * sizeof(double);
     const int nslot = (x.nb * x.shape->nblk_bp <= 2 * x.ncu) ? 8 : 2;    // latency-bound launch: four drawing waves, split by sampler kind; throughput-bound: wave 0 alone (see the kernel)
     const int wide = (x.nb == 1 || x.shape->nblk_bp >= 1024) ? 256 : 0;    // four columns of X per wave and trip (see the kernel)
@@ -1290,6 +1300,10 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
     if (!strcmp(name, "split_sums")) {
         if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "split_sums must be -1 (default: a chain alone), 0 or 1");
         x.split_sums = (int)value; drop_graph(x); return BNR_OK;
+    }
+    if (!strcmp(name, "wide_backproj")) {
+        if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "wide_backproj must be -1 (default: launches of many rounds), 0 or 1");
+        x.wide_backproj = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "spw_cap")) {
         if (value < 1 || value > 4) return fail(BNR_ERR_BAD_ARG, "spw_cap must be 1..4");

@@ -1382,6 +1382,54 @@ def test_factorization_variants_are_bitwise_equal(gpu):
                 assert np.array_equal(grp[k], alone[k]), (name, "group vs alone", n, V, R, k)
 
 
+def test_back_projection_with_one_edge_per_lane_is_bitwise_equal(gpu):
+    """k_backproj64 (a workgroup owns 64 edges, its drawing wave one edge per lane and the reference's own attempt loop: the default for launches of many rounds of
+    workgroups -- a lockstep group at large q) writes bitwise the tables of k_backproj (gibbs.jl:435-436, 454-458, 603-605): gamma, S and the per-chunk partial sums, alone
+    and as members of a group, from graphs and eagerly, with the sums inside the launch and as a launch of their own, on the f64 and on the byte image of X; edge counts that
+    end in a short chunk, in a workgroup with one chunk only, and a single chunk.  One more sweep from a state with theta = 1e-300 sends every edge through the degenerate
+    branch (gig.jl:21-26) in both kernels."""
+    for (n, V, R, binary) in [(70, 19, 5, False), (193, 30, 5, False), (64, 7, 2, False), (500, 40, 4, True), (130, 12, 3, False), (64, 150, 3, False), (40, 23, 11, False)]:
+        if binary:
+            rng = np.random.default_rng(5)
+            X = bnr_amd.XInput(np.asfortranarray(rng.random((n, V * (V + 1) // 2)) < 0.5), False)
+            y = rng.normal(size=n)
+        else:
+            X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=11)
+        tabs = {}
+        hyper = dict(nu=R + 2) if R > 8 else {}
+        for name, opts in (("32 edges per workgroup", {"wide_backproj": 0}), ("64 edges", {"wide_backproj": 1}), ("64 edges, eager", {"wide_backproj": 1, "graph": 0}),
+                           ("64 edges, sums split off", {"wide_backproj": 1, "split_sums": 1}), ("64 edges, sums inside", {"wide_backproj": 1, "split_sums": 0})):
+            ch = bnr_amd.Chain(X, y, R, 7, 3, 1, **hyper)
+            mates = [bnr_amd.Chain.like(ch, 3, c, 7) for c in (2, 3)]
+            solo = bnr_amd.Chain.like(ch, 3, 1, 7)
+            for c in [ch, solo] + mates:
+                c.init_prior()
+                if binary:
+                    c.set_option("gram_i8", 0)
+            g = bnr_amd.Group([mates[0], ch, mates[1]])
+            for k, v in opts.items():
+                g.set_option(k, v)
+                solo.set_option(k, v)
+            g.run(2, 6, 6)
+            solo.run(2, 6, 6)
+            t = solo.fetch()
+            t["theta"][5] = 1e-300                             # row 6: psi < 10 eps in the next sweep's update_D!
+            solo.load(t, 6, 6)
+            solo.run(7, 7, 7)
+            tabs[name] = (ch.fetch(1, 6), solo.fetch())
+            assert ch.counters()["chol_fail"] == 0 and solo.counters()["chol_fail"] == 0 and solo.counters()["sampler_cap"] == 0
+            g.close()
+            for c in [ch, solo] + mates:
+                c.close()
+        base = tabs["32 edges per workgroup"]
+        assert np.isfinite(base[1]["S"]).all() and (base[1]["S"][6] > 0).all()
+        for name, (grp, alone) in tabs.items():
+            for k in bo.COLUMNS:
+                assert np.array_equal(grp[k], base[0][k]), (name, "group", n, V, R, k)
+                assert np.array_equal(alone[k], base[1][k]), (name, "alone", n, V, R, k)
+                assert np.array_equal(grp[k][:5], alone[k][:5]), (name, "group vs alone", n, V, R, k)
+
+
 def test_prepare_never_changes_results(gpu, test1):
     """bnr_chain_prepare / bnr_group_prepare capture the graphs and replay them once on scratch rows: tables, iteration
     counters and event counters of a chain alone and of a lockstep group are bitwise what they are without it -- called
