@@ -859,7 +859,7 @@ static void launch_backproj(bnr_exec &x, int s, int flags)
     {
         // many rounds of workgroups (a lockstep group at large q): only the instructions per edge count -- one edge per lane of the drawing wave (k_backproj64)
         const size_t lds64 = ((size_t)x.shape->n_pad + 64 + (size_t)x.shape->R * 65 + (size_t)(3 * x.shape->R + 1) * 65) * sizeof(double);
-        const bool many_rounds = (size_t)x.nb * x.shape->nblk_bp >= (size_t)12 * x.ncu;
+        const bool many_rounds = (size_t)x.nb * x.shape->nblk_bp >= (size_t)8 * x.ncu;       // (measured: 2 528 chunks -1.3 %, 2 822 -1.3 %, 5 644 -2.4 %, 11 288 -3 %; 1 411 equal; 1 264 +0.4 %; a chain alone at the headline shape +4 %)
         if ((flags & 3) == 3 && lds64 <= 124 * 1024 && (x.wide_backproj == 1 || (x.wide_backproj < 0 && many_rounds))) {
             BNR_LAUNCH(k_backproj64, dim3(round_up((x.shape->nblk_bp + 1) / 2, 8) * x.nb), dim3(256), lds64, x.stream, x, s, flags, x.nb);
             return;
