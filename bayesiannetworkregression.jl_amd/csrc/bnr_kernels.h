@@ -555,90 +555,6 @@ __global__ __launch_bounds__(256) void k_xpass_group(const bnr_many chain_src, i
     }
 }
 
-// k_xpass_group2: k_xpass_group for long column chunks (chunk_x > 64: large q).  The column loop for NC members, straight-line: 16 columns of X in flight, the 2 NC multipliers of a column (W and sqrt(S) z1 of every member) contiguous
-// in LDS (sWZ[column][member][2]: four 16-byte reads per column for eight members).  Round 5: the earlier form -- run-time member count tested inside the unrolled loops, one
-// 8-byte LDS read per multiply-add -- waited for LDS in front of every multiply-add: 15.8 us of the kernel's 21 (in-kernel stamps, alone on the chip) for 2 x 16 columns.
-typedef double bnr_d2 __attribute__((ext_vector_type(2)));
-template <int NC, class XT>
-__device__ __forceinline__ void bnr_xg_columns(const XT *xp, size_t ld, int ne, const double *sWZ, double (&aw)[8], double (&aa)[8])
-{
-    int t0 = 0;
-    for (; t0 + 16 <= ne; t0 += 16) {
-        XT xv[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) xv[u] = xp[(size_t)(t0 + u) * ld];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const double x = (double)xv[u];
-            const bnr_d2 *o = (const bnr_d2 *)(sWZ + (size_t)(t0 + u) * 16);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) { const bnr_d2 wz = o[c]; aw[c] = fma(x, wz[0], aw[c]); aa[c] = fma(x, wz[1], aa[c]); }
-        }
-    }
-    for (; t0 < ne; ++t0) {
-        const double x = (double)xp[(size_t)t0 * ld];
-        const bnr_d2 *o = (const bnr_d2 *)(sWZ + (size_t)t0 * 16);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) { const bnr_d2 wz = o[c]; aw[c] = fma(x, wz[0], aw[c]); aa[c] = fma(x, wz[1], aa[c]); }
-    }
-}
-template <class XT>
-__device__ __forceinline__ void bnr_xg_dispatch(int nc, const XT *xp, size_t ld, int ne, const double *sWZ, double (&aw)[8], double (&aa)[8])
-{
-    switch (nc) {
-    case 1: bnr_xg_columns<1>(xp, ld, ne, sWZ, aw, aa); break;
-    case 2: bnr_xg_columns<2>(xp, ld, ne, sWZ, aw, aa); break;
-    case 3: bnr_xg_columns<3>(xp, ld, ne, sWZ, aw, aa); break;
-    case 4: bnr_xg_columns<4>(xp, ld, ne, sWZ, aw, aa); break;
-    case 5: bnr_xg_columns<5>(xp, ld, ne, sWZ, aw, aa); break;
-    case 6: bnr_xg_columns<6>(xp, ld, ne, sWZ, aw, aa); break;
-    case 7: bnr_xg_columns<7>(xp, ld, ne, sWZ, aw, aa); break;
-    default: bnr_xg_columns<8>(xp, ld, ne, sWZ, aw, aa); break;
-    }
-}
-__global__ __launch_bounds__(256) void k_xpass_group2(const bnr_many chain_src, int s, int nchains)
-{
-    if (BNR_EXP_SKIP_SCALAR()) return;
-    const bnr_dev &c0 = chain_src.at(0);                  // the geometry and the shared X, index maps
-    const int rs = (c0.n_pad + 255) / 256, bid = blockIdx.x / rs, slice = blockIdx.x % rs, tid = threadIdx.x;
-    const int chunk = c0.chunk_x, e0 = bid * chunk, ne = min(chunk, c0.q - e0), R = c0.R;
-    const size_t ld = c0.n_pad;
-    extern __shared__ double sh[];
-    double *sWZ = sh;                                      // [column of the chunk][member][W, sqrt(S) z1]
-    __shared__ double *s_pw[8], *s_pa[8];
-    const int i = slice * 256 + tid;
-    const bool live = i < c0.n_pad;                        // n_pad is a multiple of 64: the last slice may be short
-    const int ic = live ? i : 0;
-    for (int cb = 0; cb < nchains; cb += 8) {
-        const int nc = min(8, nchains - cb);
-        __syncthreads();
-        for (int it = tid; it < nc * chunk; it += 256) {
-            const int c = it / chunk, t = it - c * chunk;
-            const bnr_dev &cd = chain_src.at(cb + c);
-            const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
-            const double *row = cd.trace + (size_t)P.row * cd.rowlen, *prev = cd.trace + (size_t)P.prev * cd.rowlen;
-            double w = 0.0, zz = 0.0;
-            if (t < ne) {
-                const int e = e0 + t;
-                w = edge_W(row + cd.o_u, prev + cd.o_lam, R, cd.el[e], cd.ek[e]);
-                zz = sqrt(prev[cd.o_S + e]) * bnr_normal(cd.seed, P.it, SITE_G_Z1, (uint32_t)e, 0);
-                if (slice == 0) { cd.Wbuf[e] = w; cd.sz[e] = zz; }
-            }
-            sWZ[(size_t)t * 16 + 2 * c] = w; sWZ[(size_t)t * 16 + 2 * c + 1] = zz;
-        }
-        if (tid < nc) { const bnr_dev &cd = chain_src.at(cb + tid); s_pw[tid] = cd.PW; s_pa[tid] = cd.PA; }
-        __syncthreads();
-        double aw[8], aa[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { aw[c] = 0.0; aa[c] = 0.0; }
-        if (c0.X8) bnr_xg_dispatch(nc, c0.X8 + (size_t)e0 * ld + ic, ld, ne, sWZ, aw, aa);
-        else bnr_xg_dispatch(nc, c0.X + (size_t)e0 * ld + ic, ld, ne, sWZ, aw, aa);
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (c < nc && live) { s_pw[c][(size_t)bid * ld + i] = aw[c]; s_pa[c][(size_t)bid * ld + i] = aa[c]; }
-    }
-}
-
 // ===================================================================================== k_gram
 // G = X diag(S_prev) X'  (the n x n matrix of gibbs.jl:434 without the identity; tau cancels: Xt tau2 D Xt' = X D X').
 // v_mfma_f64_16x16x4_f64, D = A*B + C with A[m][k] (lane l: m = l&15, k = l>>4), B[k][n] (k = l>>4, n = l&15),
@@ -2272,106 +2188,6 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
     if (cap && lane < 32) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
 }
 
-// ===================================================================================== k_backproj64
-// The back-projection for launches of MANY rounds of workgroups (a lockstep group at large q: 8 chains at BASELINE configs[4] are 11 288 chunks of 32 edges, 15 rounds of
-// 768 resident workgroups): there only the number of instructions per edge counts, and k_backproj's drawing wave spends its 64 lanes on 32 edges (two speculative attempts per
-// edge and round) -- one GIG setup and one pass of the 3R + 1 terms per 32 edges.  Here a workgroup owns 64 consecutive edges (two chunks of the Psum table) and its drawing
-// wave holds one edge per lane: one setup and one pass of the terms per 64 edges, the attempts of an edge one after the other (bnr_gig's own loop, no exchange through LDS).
-// About as many attempt rounds per 64 edges (the slowest of 64 lanes against twice the slowest of 32 with two attempts each), ~25 % fewer instructions per edge
-// (profiles/round5_cfg5_roofline.txt: the launch is bound by that arithmetic).  Per edge the same arithmetic as k_backproj: the same per-lane row sums and wave reduction (gamma),
-// the first accepted attempt of bnr_gig (S), the same terms summed per chunk of 32 edges in the same order (Psum) -- bitwise the same tables.
-// Launches of one or two rounds (the headline group, a chain alone) keep k_backproj: there the draw's latency counts, and it is shorter with 32 edges per wave.
-// flags bit 2 -> partial sums; gamma and S always.  grid = round_up(ceil(nblk_bp / 2), 8) x chains.
-template <class SRC>
-__global__ __launch_bounds__(256) void k_backproj64(const SRC chain_src, int s, int flags, int nchains)
-{
-    BNR_CRITICAL_PATH();
-    const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
-    const int pid = (gr / nchains) * 8 + gx;               // this chain's pair of chunks
-    const bnr_dev &cd = chain_src.at(gr % nchains);
-    if (2 * pid >= cd.nblk_bp) return;
-    const int R = cd.R, n_pad = cd.n_pad, nterm = 1 + 3 * R;
-    extern __shared__ double sh[];                          // a4 | 64 dots | u products R x 65 | terms (3R + 1) x 65
-    double *sa = sh, *sdot = sa + n_pad, *sdr = sdot + 64, *st = sdr + R * 65;
-    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
-    double *row = cd.trace + (size_t)P.row * cd.rowlen;
-    const double *prev = cd.trace + (size_t)P.prev * cd.rowlen;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int e0 = pid * 64, ne = min(64, cd.q - e0);
-    const size_t ld = cd.n_pad;
-    const double tau2 = row[ROW_TAU2], tau = sqrt(tau2), psi = prev[ROW_THETA];
-    if (flags & 4) {
-        const double *un0 = row + cd.o_u;
-        for (int idx = tid; idx < R * 64; idx += 256) {
-            const int r = idx >> 6, ee = idx & 63;
-            double v = 0.0;
-            if (ee < ne) { const int l0 = cd.el[e0 + ee], k0 = cd.ek[e0 + ee]; v = un0[r + R * l0] * un0[r + R * k0]; }
-            sdr[r * 65 + ee] = v;
-        }
-    }
-    for (int i = tid; i < n_pad; i += 256) sa[i] = cd.a4[i];
-    __syncthreads();
-    // dot products: wave w the columns w, w + 4, ..., four in flight
-    for (int t = wave; t < ne; t += 16) {
-        const int t2 = t + 4, t3 = t + 8, t4 = t + 12;
-        const size_t oc = (size_t)(e0 + t) * ld, od = (size_t)(e0 + (t2 < ne ? t2 : t)) * ld, oe = (size_t)(e0 + (t3 < ne ? t3 : t)) * ld, of = (size_t)(e0 + (t4 < ne ? t4 : t)) * ld;
-        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-        if (cd.X8) {
-            const unsigned char *xc = cd.X8 + oc, *xd = cd.X8 + od, *xe = cd.X8 + oe, *xf = cd.X8 + of;
-#pragma unroll 4
-            for (int i = lane; i < n_pad; i += 64) { double av = sa[i]; acc0 = fma((double)xc[i], av, acc0); acc1 = fma((double)xd[i], av, acc1); acc2 = fma((double)xe[i], av, acc2); acc3 = fma((double)xf[i], av, acc3); }
-        } else {
-            const double *xc = cd.X + oc, *xd = cd.X + od, *xe = cd.X + oe, *xf = cd.X + of;
-#pragma unroll 4
-            for (int i = lane; i < n_pad; i += 64) { double av = sa[i]; acc0 = fma(xc[i], av, acc0); acc1 = fma(xd[i], av, acc1); acc2 = fma(xe[i], av, acc2); acc3 = fma(xf[i], av, acc3); }
-        }
-        acc0 = wave_sum(acc0); acc1 = wave_sum(acc1); acc2 = wave_sum(acc2); acc3 = wave_sum(acc3);
-        if (lane == 0) { sdot[t] = acc0; if (t2 < ne) sdot[t2] = acc1; if (t3 < ne) sdot[t3] = acc2; if (t4 < ne) sdot[t4] = acc3; }
-    }
-    __syncthreads();
-    if (wave != (pid & 3)) return;                         // the drawing wave rotates with the workgroup (the drawing waves that share a CU sit on different SIMDs)
-    const int e = e0 + lane;
-    const bool act = lane < ne;
-    int cap = 0;
-    double gam = 0.0, W = 0.0, Snew = 1.0;
-    if (act) {
-        W = cd.Wbuf[e];
-        const double Sp = prev[cd.o_S + e];
-        gam = tau * (cd.sz[e] + Sp * sdot[lane]) + W;
-        row[cd.o_gamma + e] = gam;
-        const double g = gam - W, chi = (g * g) / tau2;
-        Snew = bnr_gig(cd.seed, 0.5, chi, psi, P.it, (uint32_t)e, &cap);     // update_D! (gibbs.jl:454-458): the reference's own loop, one edge per lane
-        row[cd.o_S + e] = Snew;
-    }
-    if (cap) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
-    if (!(flags & 4)) return;
-    // the partial sums of update_theta! / update_Lambda! (gibbs.jl:476, 603-605): every lane its edge's terms, then lanes 0-31 sum the first chunk's and lanes 32-63 the second
-    // chunk's terms over their 32 edges in k_backproj's order
-    const double sd = sqrt(tau2 * Snew), lsd = log(sd) + 0.5 * log(2.0 * BNR_PI);
-    const double *lamp = prev + cd.o_lam;
-    st[lane] = act ? Snew : 0.0;
-    for (int r = 0; r < R; ++r) {
-        const double dr = sdr[r * 65 + lane], lr = lamp[r];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double Wc = W + (bnr_lambda_value(c) - lr) * dr;
-            const double zz = (gam - Wc) / sd;
-            st[(1 + 3 * r + c) * 65 + lane] = act ? (-0.5 * zz * zz - lsd) : 0.0;
-        }
-    }
-    bnr_wsync();
-    const int half = lane >> 5, chunk = 2 * pid + half;
-    if (chunk < cd.nblk_bp) {
-        double *ps = cd.Psum + (size_t)chunk * nterm;
-        for (int j = lane & 31; j < nterm; j += 32) {
-            double acc = 0.0;
-#pragma unroll 8
-            for (int e2 = 0; e2 < 32; ++e2) acc += st[j * 65 + 32 * half + e2];
-            ps[j] = acc;
-        }
-    }
-}
-
 // ===================================================================================== k_tail
 // One block of 1024 threads.  mask bits: 1 theta, 2 Delta, 4 M, 8 mu, 16 Lambda, 32 pi, 64 carried sums (rr, sig_q for
 // the next tau2), 128 ring wrap copy, 256 inv(M)/logdet M for the next k_node, 512 pre-draw the next tau2.
@@ -2963,6 +2779,192 @@ __global__ __launch_bounds__(256) void k_acov(const double *buf, int nsamp, int 
         for (int i = 0; i + lag < h; ++i) sacc += (x[i] - mean) * (x[i + lag] - mean);
         o[(size_t)(2 + lag) * np] = sacc / h;
         if (lag == 0) { o[0] = mean; o[(size_t)np] = sacc / (h - 1); }
+    }
+}
+
+// ----------------------------------------------------------------------------------------- kernels added late in round 5, kept BEHIND the others: the order of the
+// definitions is the order of the kernels in the code object, and a chain alone lost 1 % (k_chol_step 6.72 -> 6.83 us per launch) when they sat in the middle of it
+// k_xpass_group2: k_xpass_group for long column chunks (chunk_x > 64: large q).  The column loop for NC members, straight-line: 16 columns of X in flight, the 2 NC multipliers of a column (W and sqrt(S) z1 of every member) contiguous
+// in LDS (sWZ[column][member][2]: four 16-byte reads per column for eight members).  Round 5: the earlier form -- run-time member count tested inside the unrolled loops, one
+// 8-byte LDS read per multiply-add -- waited for LDS in front of every multiply-add: 15.8 us of the kernel's 21 (in-kernel stamps, alone on the chip) for 2 x 16 columns.
+typedef double bnr_d2 __attribute__((ext_vector_type(2)));
+template <int NC, class XT>
+__device__ __forceinline__ void bnr_xg_columns(const XT *xp, size_t ld, int ne, const double *sWZ, double (&aw)[8], double (&aa)[8])
+{
+    int t0 = 0;
+    for (; t0 + 16 <= ne; t0 += 16) {
+        XT xv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) xv[u] = xp[(size_t)(t0 + u) * ld];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const double x = (double)xv[u];
+            const bnr_d2 *o = (const bnr_d2 *)(sWZ + (size_t)(t0 + u) * 16);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { const bnr_d2 wz = o[c]; aw[c] = fma(x, wz[0], aw[c]); aa[c] = fma(x, wz[1], aa[c]); }
+        }
+    }
+    for (; t0 < ne; ++t0) {
+        const double x = (double)xp[(size_t)t0 * ld];
+        const bnr_d2 *o = (const bnr_d2 *)(sWZ + (size_t)t0 * 16);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { const bnr_d2 wz = o[c]; aw[c] = fma(x, wz[0], aw[c]); aa[c] = fma(x, wz[1], aa[c]); }
+    }
+}
+template <class XT>
+__device__ __forceinline__ void bnr_xg_dispatch(int nc, const XT *xp, size_t ld, int ne, const double *sWZ, double (&aw)[8], double (&aa)[8])
+{
+    switch (nc) {
+    case 1: bnr_xg_columns<1>(xp, ld, ne, sWZ, aw, aa); break;
+    case 2: bnr_xg_columns<2>(xp, ld, ne, sWZ, aw, aa); break;
+    case 3: bnr_xg_columns<3>(xp, ld, ne, sWZ, aw, aa); break;
+    case 4: bnr_xg_columns<4>(xp, ld, ne, sWZ, aw, aa); break;
+    case 5: bnr_xg_columns<5>(xp, ld, ne, sWZ, aw, aa); break;
+    case 6: bnr_xg_columns<6>(xp, ld, ne, sWZ, aw, aa); break;
+    case 7: bnr_xg_columns<7>(xp, ld, ne, sWZ, aw, aa); break;
+    default: bnr_xg_columns<8>(xp, ld, ne, sWZ, aw, aa); break;
+    }
+}
+__global__ __launch_bounds__(256) void k_xpass_group2(const bnr_many chain_src, int s, int nchains)
+{
+    if (BNR_EXP_SKIP_SCALAR()) return;
+    const bnr_dev &c0 = chain_src.at(0);                  // the geometry and the shared X, index maps
+    const int rs = (c0.n_pad + 255) / 256, bid = blockIdx.x / rs, slice = blockIdx.x % rs, tid = threadIdx.x;
+    const int chunk = c0.chunk_x, e0 = bid * chunk, ne = min(chunk, c0.q - e0), R = c0.R;
+    const size_t ld = c0.n_pad;
+    extern __shared__ double sh[];
+    double *sWZ = sh;                                      // [column of the chunk][member][W, sqrt(S) z1]
+    __shared__ double *s_pw[8], *s_pa[8];
+    const int i = slice * 256 + tid;
+    const bool live = i < c0.n_pad;                        // n_pad is a multiple of 64: the last slice may be short
+    const int ic = live ? i : 0;
+    for (int cb = 0; cb < nchains; cb += 8) {
+        const int nc = min(8, nchains - cb);
+        __syncthreads();
+        for (int it = tid; it < nc * chunk; it += 256) {
+            const int c = it / chunk, t = it - c * chunk;
+            const bnr_dev &cd = chain_src.at(cb + c);
+            const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
+            const double *row = cd.trace + (size_t)P.row * cd.rowlen, *prev = cd.trace + (size_t)P.prev * cd.rowlen;
+            double w = 0.0, zz = 0.0;
+            if (t < ne) {
+                const int e = e0 + t;
+                w = edge_W(row + cd.o_u, prev + cd.o_lam, R, cd.el[e], cd.ek[e]);
+                zz = sqrt(prev[cd.o_S + e]) * bnr_normal(cd.seed, P.it, SITE_G_Z1, (uint32_t)e, 0);
+                if (slice == 0) { cd.Wbuf[e] = w; cd.sz[e] = zz; }
+            }
+            sWZ[(size_t)t * 16 + 2 * c] = w; sWZ[(size_t)t * 16 + 2 * c + 1] = zz;
+        }
+        if (tid < nc) { const bnr_dev &cd = chain_src.at(cb + tid); s_pw[tid] = cd.PW; s_pa[tid] = cd.PA; }
+        __syncthreads();
+        double aw[8], aa[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { aw[c] = 0.0; aa[c] = 0.0; }
+        if (c0.X8) bnr_xg_dispatch(nc, c0.X8 + (size_t)e0 * ld + ic, ld, ne, sWZ, aw, aa);
+        else bnr_xg_dispatch(nc, c0.X + (size_t)e0 * ld + ic, ld, ne, sWZ, aw, aa);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < nc && live) { s_pw[c][(size_t)bid * ld + i] = aw[c]; s_pa[c][(size_t)bid * ld + i] = aa[c]; }
+    }
+}
+
+// ===================================================================================== k_backproj64
+// The back-projection for launches of MANY rounds of workgroups (a lockstep group at large q: 8 chains at BASELINE configs[4] are 11 288 chunks of 32 edges, 15 rounds of
+// 768 resident workgroups): there only the number of instructions per edge counts, and k_backproj's drawing wave spends its 64 lanes on 32 edges (two speculative attempts per
+// edge and round) -- one GIG setup and one pass of the 3R + 1 terms per 32 edges.  Here a workgroup owns 64 consecutive edges (two chunks of the Psum table) and its drawing
+// wave holds one edge per lane: one setup and one pass of the terms per 64 edges, the attempts of an edge one after the other (bnr_gig's own loop, no exchange through LDS).
+// About as many attempt rounds per 64 edges (the slowest of 64 lanes against twice the slowest of 32 with two attempts each), ~25 % fewer instructions per edge
+// (profiles/round5_cfg5_roofline.txt: the launch is bound by that arithmetic).  Per edge the same arithmetic as k_backproj: the same per-lane row sums and wave reduction (gamma),
+// the first accepted attempt of bnr_gig (S), the same terms summed per chunk of 32 edges in the same order (Psum) -- bitwise the same tables.
+// Launches of one or two rounds (the headline group, a chain alone) keep k_backproj: there the draw's latency counts, and it is shorter with 32 edges per wave.
+// flags bit 2 -> partial sums; gamma and S always.  grid = round_up(ceil(nblk_bp / 2), 8) x chains.
+template <class SRC>
+__global__ __launch_bounds__(256) void k_backproj64(const SRC chain_src, int s, int flags, int nchains)
+{
+    BNR_CRITICAL_PATH();
+    const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
+    const int pid = (gr / nchains) * 8 + gx;               // this chain's pair of chunks
+    const bnr_dev &cd = chain_src.at(gr % nchains);
+    if (2 * pid >= cd.nblk_bp) return;
+    const int R = cd.R, n_pad = cd.n_pad, nterm = 1 + 3 * R;
+    extern __shared__ double sh[];                          // a4 | 64 dots | u products R x 65 | terms (3R + 1) x 65
+    double *sa = sh, *sdot = sa + n_pad, *sdr = sdot + 64, *st = sdr + R * 65;
+    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
+    double *row = cd.trace + (size_t)P.row * cd.rowlen;
+    const double *prev = cd.trace + (size_t)P.prev * cd.rowlen;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int e0 = pid * 64, ne = min(64, cd.q - e0);
+    const size_t ld = cd.n_pad;
+    const double tau2 = row[ROW_TAU2], tau = sqrt(tau2), psi = prev[ROW_THETA];
+    if (flags & 4) {
+        const double *un0 = row + cd.o_u;
+        for (int idx = tid; idx < R * 64; idx += 256) {
+            const int r = idx >> 6, ee = idx & 63;
+            double v = 0.0;
+            if (ee < ne) { const int l0 = cd.el[e0 + ee], k0 = cd.ek[e0 + ee]; v = un0[r + R * l0] * un0[r + R * k0]; }
+            sdr[r * 65 + ee] = v;
+        }
+    }
+    for (int i = tid; i < n_pad; i += 256) sa[i] = cd.a4[i];
+    __syncthreads();
+    // dot products: wave w the columns w, w + 4, ..., four in flight
+    for (int t = wave; t < ne; t += 16) {
+        const int t2 = t + 4, t3 = t + 8, t4 = t + 12;
+        const size_t oc = (size_t)(e0 + t) * ld, od = (size_t)(e0 + (t2 < ne ? t2 : t)) * ld, oe = (size_t)(e0 + (t3 < ne ? t3 : t)) * ld, of = (size_t)(e0 + (t4 < ne ? t4 : t)) * ld;
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        if (cd.X8) {
+            const unsigned char *xc = cd.X8 + oc, *xd = cd.X8 + od, *xe = cd.X8 + oe, *xf = cd.X8 + of;
+#pragma unroll 4
+            for (int i = lane; i < n_pad; i += 64) { double av = sa[i]; acc0 = fma((double)xc[i], av, acc0); acc1 = fma((double)xd[i], av, acc1); acc2 = fma((double)xe[i], av, acc2); acc3 = fma((double)xf[i], av, acc3); }
+        } else {
+            const double *xc = cd.X + oc, *xd = cd.X + od, *xe = cd.X + oe, *xf = cd.X + of;
+#pragma unroll 4
+            for (int i = lane; i < n_pad; i += 64) { double av = sa[i]; acc0 = fma(xc[i], av, acc0); acc1 = fma(xd[i], av, acc1); acc2 = fma(xe[i], av, acc2); acc3 = fma(xf[i], av, acc3); }
+        }
+        acc0 = wave_sum(acc0); acc1 = wave_sum(acc1); acc2 = wave_sum(acc2); acc3 = wave_sum(acc3);
+        if (lane == 0) { sdot[t] = acc0; if (t2 < ne) sdot[t2] = acc1; if (t3 < ne) sdot[t3] = acc2; if (t4 < ne) sdot[t4] = acc3; }
+    }
+    __syncthreads();
+    if (wave != (pid & 3)) return;                         // the drawing wave rotates with the workgroup (the drawing waves that share a CU sit on different SIMDs)
+    const int e = e0 + lane;
+    const bool act = lane < ne;
+    int cap = 0;
+    double gam = 0.0, W = 0.0, Snew = 1.0;
+    if (act) {
+        W = cd.Wbuf[e];
+        const double Sp = prev[cd.o_S + e];
+        gam = tau * (cd.sz[e] + Sp * sdot[lane]) + W;
+        row[cd.o_gamma + e] = gam;
+        const double g = gam - W, chi = (g * g) / tau2;
+        Snew = bnr_gig(cd.seed, 0.5, chi, psi, P.it, (uint32_t)e, &cap);     // update_D! (gibbs.jl:454-458): the reference's own loop, one edge per lane
+        row[cd.o_S + e] = Snew;
+    }
+    if (cap) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
+    if (!(flags & 4)) return;
+    // the partial sums of update_theta! / update_Lambda! (gibbs.jl:476, 603-605): every lane its edge's terms, then lanes 0-31 sum the first chunk's and lanes 32-63 the second
+    // chunk's terms over their 32 edges in k_backproj's order
+    const double sd = sqrt(tau2 * Snew), lsd = log(sd) + 0.5 * log(2.0 * BNR_PI);
+    const double *lamp = prev + cd.o_lam;
+    st[lane] = act ? Snew : 0.0;
+    for (int r = 0; r < R; ++r) {
+        const double dr = sdr[r * 65 + lane], lr = lamp[r];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double Wc = W + (bnr_lambda_value(c) - lr) * dr;
+            const double zz = (gam - Wc) / sd;
+            st[(1 + 3 * r + c) * 65 + lane] = act ? (-0.5 * zz * zz - lsd) : 0.0;
+        }
+    }
+    bnr_wsync();
+    const int half = lane >> 5, chunk = 2 * pid + half;
+    if (chunk < cd.nblk_bp) {
+        double *ps = cd.Psum + (size_t)chunk * nterm;
+        for (int j = lane & 31; j < nterm; j += 32) {
+            double acc = 0.0;
+#pragma unroll 8
+            for (int e2 = 0; e2 < 32; ++e2) acc += st[j * 65 + 32 * half + e2];
+            ps[j] = acc;
+        }
     }
 }
 
