@@ -257,6 +257,9 @@ int bnr_debug_set_exp(int32_t device, int32_t flags);
  *   "split_sums" -1 (default): a chain run alone computes the back-projection's partial sums (update_theta!, update_Lambda!) in a launch of
  *               their own in front of the scalar tail, off the critical chain; 1: always; 0: inside the back-projection
  *   "spw_cap"   1..4 (default 4): super blocks per update workgroup of the factorization, at most (diagnostics)
+ *   "wide_backproj" -1 (default): launches of the back-projection with 8 x CUs or more chunks of 32 edges (a lockstep group at large q) run k_backproj64 --
+ *               a workgroup owns 64 edges, its drawing wave one edge per lane and the reference's own attempt loop (fewer instructions per edge; launches of one or
+ *               two rounds of workgroups keep k_backproj, whose draws have the shorter latency); 1: always; 0: never.  Bitwise the same tables.
  *   Experiments ("nop_fork", "pipeline", "gate_us", "linear", "linear_merge", "linear_debug", "group_backproj", "resv_mask", "crit_origin"; rounds 3-4,
  *               profiles/round*_experiments_notes.txt): all measured no faster, part of them polled device memory.  Removed from the tree in
  *               round 5 (tools/experiments/README.md): the library refuses them by name.
