@@ -1,5 +1,5 @@
 """Randomised parity sweep: random (n, V, R, seed, X flavour, hyper-parameters), a few Gibbs sweeps on the GPU (alone or as a
-member of a lockstep group) against the CPU oracle on identical variates.  usage: fuzz_shapes.py <cases> [seed] [scale | binary]"""
+member of a lockstep group) against the CPU oracle on identical variates.  usage: fuzz_shapes.py <cases> [seed] [scale | binary]   (BNR_FUZZ_OPTS=name=value,...: chain / group options set before the run)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bnr_amd
@@ -30,6 +30,8 @@ for case in range(N):
         for c in mates: c.set_option("gram_i8", 1)
     for c in [ch] + mates: c.init_prior()
     g = bnr_amd.Group(mates[:1] + [ch] + mates[1:]) if group else None
+    for kv in os.environ.get("BNR_FUZZ_OPTS", "").split(","):        # e.g. BNR_FUZZ_OPTS=wide_backproj=1: the whole sweep under a non-default kernel choice
+        if kv: (g or ch).set_option(kv.split("=")[0], int(kv.split("=")[1]))
     (g or ch).run(2, tot, tot)
     got = ch.fetch()
     o = bo.Oracle(X, y, R, tot, seed, chain=1, pdf_mode=1, **hyper); o.init_prior(); o.run(2, tot, tot)
