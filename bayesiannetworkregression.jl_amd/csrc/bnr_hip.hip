@@ -140,6 +140,10 @@ static void forget_alloc(bnr_chain *c, void *p)
 
 // Dynamic LDS beyond 64 KiB needs the function attribute, and the attribute is per DEVICE: set once per device of this
 // process, after hipSetDevice, under a lock (handles may be created from several host threads); failures are reported at create.
+struct bnr_exec;
+static int late_kernels_lds_attributes(int bytes);
+static void launch_late_xpass_group2(bnr_exec &x, int s);
+static void launch_late_backproj64(bnr_exec &x, int s, int flags, size_t lds64);
 static int ensure_lds_attributes(int device)
 {
     static std::mutex mu;
@@ -150,8 +154,11 @@ static int ensure_lds_attributes(int device)
     const int big = 124 * 1024;
     const void *fns[] = {(const void *)&k_tail<bnr_one>, (const void *)&k_tail<bnr_many>, (const void *)&k_backproj<bnr_one>,
                          (const void *)&k_backproj<bnr_many>, (const void *)&k_solve_a4<bnr_one>, (const void *)&k_solve_a4<bnr_many>,
-                         (const void *)&k_xpass_group, (const void *)&k_xpass_group2, (const void *)&k_backproj64<bnr_one>, (const void *)&k_backproj64<bnr_many>, (const void *)&k_node<bnr_one>, (const void *)&k_node<bnr_many>};   // (k_node: 66.5 KB at R = 32)
+                         (const void *)&k_xpass_group, (const void *)&k_node<bnr_one>, (const void *)&k_node<bnr_many>};   // (k_node: 66.5 KB at R = 32)
     for (const void *f : fns) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    if (int rc = late_kernels_lds_attributes(big)) return rc;   // (defined at the end of this file, like every other reference to the kernels added late in round 5: the order of
+                                                                // first reference is the order of the instantiations in the code object, and a chain alone is 1 % slower when
+                                                                // those kernels sit in the middle of it)
     done[device] = 1;
     return BNR_OK;
 }
@@ -677,7 +684,7 @@ static void launch_xpass(bnr_exec &x, int s, int which)
         // one workgroup per column chunk and row slice for all members: X comes out of the L2s once, not once per chain
         // long column chunks (large q: 177 columns per workgroup at config 5): the straight-line column loop -- config 5 x 8 chains, where the scalar branch is the longer
         // chain behind the Gram; at the headline shape (32 columns per workgroup) it brought nothing per sweep (notes S), so short chunks keep the first kernel
-        if (x.shape->chunk_x > 64) hipLaunchKernelGGL(k_xpass_group2, dim3(x.shape->nblk_x * ((x.shape->n_pad + 255) / 256)), dim3(256), 16 * x.shape->chunk_x * sizeof(double), x.stream, bnr_many{x.cds}, s, x.nb);
+        if (x.shape->chunk_x > 64) launch_late_xpass_group2(x, s);
         else hipLaunchKernelGGL(k_xpass_group, dim3(x.shape->nblk_x * ((x.shape->n_pad + 255) / 256)), dim3(256), 16 * x.shape->chunk_x * sizeof(double), x.stream, bnr_many{x.cds}, s, x.nb);
         return;
     }
@@ -861,7 +868,7 @@ static void launch_backproj(bnr_exec &x, int s, int flags)
         const size_t lds64 = ((size_t)x.shape->n_pad + 64 + (size_t)x.shape->R * 65 + (size_t)(3 * x.shape->R + 1) * 65) * sizeof(double);
         const bool many_rounds = (size_t)x.nb * x.shape->nblk_bp >= (size_t)8 * x.ncu;       // (measured: 2 528 chunks -1.3 %, 2 822 -1.3 %, 5 644 -2.4 %, 11 288 -3 %; 1 411 equal; 1 264 +0.4 %; a chain alone at the headline shape +4 %)
         if ((flags & 3) == 3 && lds64 <= 124 * 1024 && (x.wide_backproj == 1 || (x.wide_backproj < 0 && many_rounds))) {
-            BNR_LAUNCH(k_backproj64, dim3(round_up((x.shape->nblk_bp + 1) / 2, 8) * x.nb), dim3(256), lds64, x.stream, x, s, flags, x.nb);
+            launch_late_backproj64(x, s, flags, lds64);
             return;
         }
     }
@@ -871,7 +878,13 @@ static void launch_backproj(bnr_exec &x, int s, int flags)
     BNR_LAUNCH(k_backproj, dim3(round_up(x.shape->nblk_bp, 8) * x.nb), dim3(256), lds, x.stream, x, s, flags | wide, x.nb, nslot);
 }
 static void launch_tail(bnr_exec &x, int s, int mask, int xg_src)
-{ BNR_LAUNCH(k_tail, dim3(1, 1, x.nb), dim3(BNR_TAIL_THREADS), (size_t)x.shape->R * x.shape->V <= BNR_TAIL_U_LDS ? (size_t)x.shape->R * x.shape->V * sizeof(double) : 0, x.stream, x, s, mask, xg_src); }
+{
+    const size_t rv = (size_t)x.shape->R * x.shape->V;
+    if (rv <= BNR_TAIL_U_LDS) { BNR_LAUNCH(k_tail, dim3(1, 1, x.nb), dim3(BNR_TAIL_THREADS), rv * sizeof(double), x.stream, x, s, mask, xg_src); return; }
+    // u beyond the LDS budget: the instantiation that reads it from the table row
+    if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tail<bnr_one, false>), dim3(1, 1, 1), dim3(BNR_TAIL_THREADS), 0, x.stream, bnr_one{*x.shape}, s, mask, xg_src);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tail<bnr_many, false>), dim3(1, 1, x.nb), dim3(BNR_TAIL_THREADS), 0, x.stream, bnr_many{x.cds}, s, mask, xg_src);
+}
 // The scalar tail of sweep s with everything it needs: with split_sums the per-block partial sums of update_theta! / update_Lambda!
 // (gibbs.jl:476, 603-605) are not computed by the back-projection on the critical chain but by a launch of their own in front of the tail --
 // the same kernel with flags = 4, the same sums in the same order.
@@ -2199,3 +2212,17 @@ int bnr_chain_set_option(bnr_chain *c, const char *name, int64_t value)
 }
 
 }  // extern "C"
+
+// ----------------------------------------------------------------------------------------- every reference to the kernels added late in round 5 (see ensure_lds_attributes)
+extern "C++" {
+static int late_kernels_lds_attributes(int bytes)
+{
+    const void *late[] = {(const void *)&k_xpass_group2<0>, (const void *)&k_backproj64<bnr_one>, (const void *)&k_backproj64<bnr_many>};
+    for (const void *f : late) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return BNR_OK;
+}
+static void launch_late_xpass_group2(bnr_exec &x, int s)
+{ hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xpass_group2<0>), dim3(x.shape->nblk_x * ((x.shape->n_pad + 255) / 256)), dim3(256), 16 * x.shape->chunk_x * sizeof(double), x.stream, bnr_many{x.cds}, s, x.nb); }
+static void launch_late_backproj64(bnr_exec &x, int s, int flags, size_t lds64)
+{ BNR_LAUNCH(k_backproj64, dim3(round_up((x.shape->nblk_bp + 1) / 2, 8) * x.nb), dim3(256), lds64, x.stream, x, s, flags, x.nb); }
+}

@@ -982,47 +982,6 @@ __global__ void k_x_mask(const unsigned char *X8, int n, int n_pad, int q, int k
     *(bnr_i4 *)(XM + (size_t)i * kslab + 16 * (size_t)g) = out;
     if (bad) *not_binary = 1;
 }
-template <class SRC, int L>
-__global__ __launch_bounds__(1024) void k_sdigits(const SRC chain_src, int s)
-{
-    const bnr_dev &cd = chain_src.get_x();                    // grid = (chains, slices): every workgroup finds the largest S itself (q values out of the L2: the maximum does
-                                                              // not depend on who computes it) and converts its slice of the entries -- one workgroup per chain took 38 us at
-                                                              // q = 45 150 on the critical chain in front of the i8 Gram (round 5, third session)
-    const int tid = threadIdx.x;
-    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
-    const double *S = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
-    __shared__ double red[16];
-    double m = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
-    int k = tid;
-    for (; k + 3072 < cd.q; k += 4096) { m = fmax(m, S[k]); m1 = fmax(m1, S[k + 1024]); m2 = fmax(m2, S[k + 2048]); m3 = fmax(m3, S[k + 3072]); }
-    for (; k < cd.q; k += 1024) m = fmax(m, S[k]);
-    m = fmax(fmax(m, m1), fmax(m2, m3));
-    m = fmax(m, __shfl_xor(m, 32)); m = fmax(m, __shfl_xor(m, 16)); m = fmax(m, __shfl_xor(m, 8));
-    m = fmax(m, __shfl_xor(m, 4)); m = fmax(m, __shfl_xor(m, 2)); m = fmax(m, __shfl_xor(m, 1));
-    if ((tid & 63) == 0) red[tid >> 6] = m;
-    __syncthreads();
-    m = red[0];
-    for (int w = 1; w < 16; ++w) m = fmax(m, red[w]);
-    int e;
-    (void)frexp(m, &e);                                       // m = f 2^e with f in [0.5, 1): every S_k < 2^e
-    constexpr int BITS = 8 * L - 2;                           // S_k up < 2^BITS <= 2^62: the top digit stays below 64, a carry cannot overflow it
-    const double up = ldexp(1.0, BITS - e);
-    if (tid == 0 && blockIdx.y == 0) cd.scal[SC_I8SCALE] = ldexp(1.0, e - BITS);
-    const int kchunk = cd.q_pad / cd.ksplit;
-    for (int idx = (int)blockIdx.y * 1024 + tid; idx < cd.kslab; idx += (int)gridDim.y * 1024) {
-        const int ks = idx / cd.kcp, kk = idx % cd.kcp, k = ks * kchunk + kk;
-        unsigned long long N = 0;
-        if (kk < kchunk && k < cd.q) N = (unsigned long long)(S[k] * up);
-        // balanced base-256 digits, least significant first: a byte >= 128 stands for byte - 256 and carries one into the next
-        unsigned carry = 0;
-#pragma unroll
-        for (int l = L - 1; l >= 0; --l) {
-            const unsigned b = (unsigned)((N >> (8 * (L - 1 - l))) & 255ull) + carry;
-            carry = b >= 128u ? 1u : 0u;
-            cd.Sdig[(size_t)l * cd.kslab + idx] = (unsigned char)(b & 255u);
-        }
-    }
-}
 // one (tile, K slice) task per 256-thread workgroup; dynamic LDS = 2 buffers x [I tile | J tile] x 64 rows x 144 bytes + L x kcp bytes of digits
 #define BNR_I8_RS 144                                         // bytes per staged row: 128 (two k-steps) + 16 of padding -- conflict-free ds_read_b128 fragments
 #define BNR_I8_TB (64 * BNR_I8_RS)
@@ -2242,7 +2201,9 @@ __device__ inline void wave_tri_inverse(const double *A, double *T, int R, int l
                                // count, so another value changes their last bits (the tables then differ from this build's by rounding; round 3's 1024-thread
                                // build differs from this one in exactly that way -- within 1e-9 of each other and of the CPU restatement the tests check against, not bit for bit)
 static_assert(BNR_TAIL_THREADS == 512, "k_tail's reductions depend on its thread count: see the note above");
-template <class SRC>
+// (ULDS: u staged in LDS -- the kernel of rounds 1-5 -- or read from the table row (R V beyond BNR_TAIL_U_LDS): two instantiations, so that the common one carries neither the
+// test nor the second copy of the loops)
+template <class SRC, bool ULDS = true>
 __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, int s, int mask, int xg_src)
 {
     const bnr_dev &cd = chain_src.get();
@@ -2270,7 +2231,7 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
     BNR_TSTAMP(0);
     if (tid < R) slam[tid] = row[cd.o_lam + tid];
     if (tid == 0) { sval[1] = row[ROW_MU]; sflag[0] = 0; sflag[1] = 0; }
-    const bool u_lds = R * V <= BNR_TAIL_U_LDS;
+    constexpr bool u_lds = ULDS;
     if (u_lds) for (int i = tid; i < R * V; i += blockDim.x) su_lds[i] = row[cd.o_u + i];
     const double *su_row = row + cd.o_u;          // (the two sources stay two pointers with their own address spaces: one pointer selected at run time is a generic one, and the
                                                   // q pass below then reads u by flat loads -- config 5, one chain: 414 instead of 396 us per sweep)
@@ -2825,6 +2786,7 @@ __device__ __forceinline__ void bnr_xg_dispatch(int nc, const XT *xp, size_t ld,
     default: bnr_xg_columns<8>(xp, ld, ne, sWZ, aw, aa); break;
     }
 }
+template <int LATE>     // (a template only so that the kernel is emitted behind the others, with the instantiations: see the note above)
 __global__ __launch_bounds__(256) void k_xpass_group2(const bnr_many chain_src, int s, int nchains)
 {
     if (BNR_EXP_SKIP_SCALAR()) return;
@@ -2968,3 +2930,45 @@ __global__ __launch_bounds__(256) void k_backproj64(const SRC chain_src, int s, 
     }
 }
 
+// (k_sdigits grew in the third session -- several workgroups per chain -- and moved here with the late kernels: see the note above)
+template <class SRC, int L>
+__global__ __launch_bounds__(1024) void k_sdigits(const SRC chain_src, int s)
+{
+    const bnr_dev &cd = chain_src.get_x();                    // grid = (chains, slices): every workgroup finds the largest S itself (q values out of the L2: the maximum does
+                                                              // not depend on who computes it) and converts its slice of the entries -- one workgroup per chain took 38 us at
+                                                              // q = 45 150 on the critical chain in front of the i8 Gram (round 5, third session)
+    const int tid = threadIdx.x;
+    const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
+    const double *S = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
+    __shared__ double red[16];
+    double m = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+    int k = tid;
+    for (; k + 3072 < cd.q; k += 4096) { m = fmax(m, S[k]); m1 = fmax(m1, S[k + 1024]); m2 = fmax(m2, S[k + 2048]); m3 = fmax(m3, S[k + 3072]); }
+    for (; k < cd.q; k += 1024) m = fmax(m, S[k]);
+    m = fmax(fmax(m, m1), fmax(m2, m3));
+    m = fmax(m, __shfl_xor(m, 32)); m = fmax(m, __shfl_xor(m, 16)); m = fmax(m, __shfl_xor(m, 8));
+    m = fmax(m, __shfl_xor(m, 4)); m = fmax(m, __shfl_xor(m, 2)); m = fmax(m, __shfl_xor(m, 1));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = red[0];
+    for (int w = 1; w < 16; ++w) m = fmax(m, red[w]);
+    int e;
+    (void)frexp(m, &e);                                       // m = f 2^e with f in [0.5, 1): every S_k < 2^e
+    constexpr int BITS = 8 * L - 2;                           // S_k up < 2^BITS <= 2^62: the top digit stays below 64, a carry cannot overflow it
+    const double up = ldexp(1.0, BITS - e);
+    if (tid == 0 && blockIdx.y == 0) cd.scal[SC_I8SCALE] = ldexp(1.0, e - BITS);
+    const int kchunk = cd.q_pad / cd.ksplit;
+    for (int idx = (int)blockIdx.y * 1024 + tid; idx < cd.kslab; idx += (int)gridDim.y * 1024) {
+        const int ks = idx / cd.kcp, kk = idx % cd.kcp, k = ks * kchunk + kk;
+        unsigned long long N = 0;
+        if (kk < kchunk && k < cd.q) N = (unsigned long long)(S[k] * up);
+        // balanced base-256 digits, least significant first: a byte >= 128 stands for byte - 256 and carries one into the next
+        unsigned carry = 0;
+#pragma unroll
+        for (int l = L - 1; l >= 0; --l) {
+            const unsigned b = (unsigned)((N >> (8 * (L - 1 - l))) & 255ull) + carry;
+            carry = b >= 128u ? 1u : 0u;
+            cd.Sdig[(size_t)l * cd.kslab + idx] = (unsigned char)(b & 255u);
+        }
+    }
+}
