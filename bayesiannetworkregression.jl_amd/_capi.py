@@ -94,6 +94,7 @@ _SIGS = {
     "bnr_host_gamma": (C.c_double, [C.c_uint64, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32]),
     "bnr_host_gig": (C.c_double, [C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32]),
     "bnr_host_edge_index": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    "bnr_host_gram_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
 }
 for _u in ("tau2", "u_xi", "gamma", "D", "theta", "Delta", "M", "mu", "Lambda", "pi"):
     _SIGS["bnr_update_" + _u] = (C.c_int, [C.c_void_p, C.c_int32, C.c_int64])

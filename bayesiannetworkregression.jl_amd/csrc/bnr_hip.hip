@@ -142,7 +142,7 @@ static void forget_alloc(bnr_chain *c, void *p)
 // process, after hipSetDevice, under a lock (handles may be created from several host threads); failures are reported at create.
 struct bnr_exec;
 static int late_kernels_lds_attributes(int bytes);
-static void launch_late_xpass_group2(bnr_exec &x, int s);
+static void launch_late_xpass_group2(bnr_exec &x, int s, unsigned grid, size_t lds, int tail_mask);
 static void launch_late_backproj64(bnr_exec &x, int s, int flags, size_t lds64);
 static int ensure_lds_attributes(int device)
 {
@@ -265,6 +265,53 @@ static int upload_x(bnr_chain *c, const x_source &src, double *Xd, unsigned char
 }
 
 // donor != NULL: share the donor's device inputs instead of uploading X, y (bnr_chain_create_like)
+// The Gram's K split (gibbs.jl:434's product, split-K over workgroups).  Chosen so that a ONE-chain Gram launch fills the chip in whole rounds of
+// one workgroup per CU: a grid of 288 workgroups on 256 CUs runs two rounds and takes twice as long as one of 252 (measured: 58 vs 31 us).  Two
+// 512-thread workgroups fit a CU, but splitting K further to use both slots of a single chain's launch only doubles the split-K partials
+// (measured: ksplit 14 vs 7 at n=500, V=100: one chain 211 vs 208 us per sweep, a group of 8 chains 468 vs 446 us); a lockstep group fills the
+// second slot with the next chain's workgroups.
+// ... and raised, whatever the above chose, until a K-group's slice (with its prefetch distance) fits the 2 GiB window of the buffer resource the
+// loops address X through (32-bit scalar byte offsets; ADVICE r5: n = 14 000 with V >= 280, n = 8 000 with V >= 520 overflowed silently).
+// Returns non-zero when no split of at most 4096 slices fits.
+static int gram_plan(int n_pad, int q, int ncu, int kg, int forced_split, int *kg_out, int *ksplit_out, int *kchunk_out)
+{
+    const int ntile = n_pad / BNR_GT, ntl = ntile * (ntile + 1) / 2;
+    auto best_split = [&](int slots) {
+        double best = -1.0;
+        int bk = 1;
+        for (int ks = 1; ks <= 32; ++ks) {
+            if (ks > 1 && (q + ks - 1) / ks < 32 * kg) break;  // keep every K-group at least 32 columns long
+            long tasks = (long)ntl * ks;
+            double eff = (double)tasks / (double)(((tasks + slots - 1) / slots) * slots);
+            double score = eff - 0.005 * ks;                              // fewer split-K partials when efficiency ties
+            if (score > best) { best = score; bk = ks; }
+        }
+        return bk;
+    };
+    // long K (>= 1024 columns per slice even when both slots of every CU are used): the partials are cheap next to the
+    // loop, fill both slots (n=500, V=300: 240 vs 262 us per Gram); otherwise one workgroup per CU
+    int ksplit = best_split(2 * ncu * (kg == 2 ? 1 : 0) + ncu * (kg == 2 ? 0 : 1));
+    if (q / ksplit < 1024) ksplit = best_split(ncu);
+    if (forced_split > 0) ksplit = forced_split;
+    auto chunk_of = [&](int ks) { return round_up((q + ks - 1) / ks, 8 * kg); };
+    const long long window = 0x7FFFFFFFLL;
+    while (bnr_gram_span_bytes(n_pad, chunk_of(ksplit), kg) > window && ksplit < 4096) ++ksplit;
+    if (bnr_gram_span_bytes(n_pad, chunk_of(ksplit), kg) > window) return 1;
+    *kg_out = kg; *ksplit_out = ksplit; *kchunk_out = chunk_of(ksplit);
+    return 0;
+}
+int bnr_host_gram_plan(int32_t n, int32_t V, int32_t ncu, int32_t out[4])
+{
+    if (!out || n < 1 || V < 2 || ncu < 1) return fail(BNR_ERR_BAD_ARG, "bnr_host_gram_plan: bad argument");
+    const int n_pad = round_up(n, BNR_GT);
+    const long long q = (long long)V * (V + 1) / 2;
+    if (q > 0x7FFFFFFF / 2) return fail(BNR_ERR_BAD_ARG, "bnr_host_gram_plan: V too large");
+    int kg = 2, ksplit = 0, kchunk = 0;
+    if (gram_plan(n_pad, (int)q, ncu, 2, 0, &kg, &ksplit, &kchunk)) return fail(BNR_ERR_BAD_ARG, "no K split fits the 2 GiB window");
+    const long long span = bnr_gram_span_bytes(n_pad, kchunk, kg);
+    out[0] = ksplit; out[1] = kchunk; out[2] = kchunk * ksplit; out[3] = (int32_t)(span >> 20);
+    return BNR_OK;
+}
 static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, const x_source &xs, const double *y, const bnr_hyper *hyper,
                        uint64_t seed, int32_t chain_id, int32_t device, int32_t tot_save, bnr_chain **out)
 {
@@ -290,35 +337,15 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     d.n_pad = round_up(n, BNR_GT);
     d.ntile = d.n_pad / BNR_GT;
     const int ntl = d.ntile * (d.ntile + 1) / 2;
-    // split K so that a ONE-chain Gram launch fills the chip in whole rounds of one workgroup per CU: a grid of 288 workgroups
-    // on 256 CUs runs two rounds and takes twice as long as one of 252 (measured: 58 vs 31 us).  Two 512-thread workgroups fit a
-    // CU, but splitting K further to use both slots of a single chain's launch only doubles the split-K partials (measured:
-    // ksplit 14 vs 7 at n=500, V=100: one chain 211 vs 208 us per sweep, a group of 8 chains 468 vs 446 us); a lockstep
-    // group fills the second slot with the next chain's workgroups.
     {
         hipDeviceProp_t prop;
         int ncu = 256;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
         const char *ev = getenv("BNR_GRAM_KG");
-        d.gram_kg = (ev && atoi(ev) == 4) ? 4 : 2;
-        auto best_split = [&](int slots) {
-            double best = -1.0;
-            int bk = 1;
-            for (int ks = 1; ks <= 32; ++ks) {
-                if (ks > 1 && (d.q + ks - 1) / ks < 32 * d.gram_kg) break;  // keep every K-group at least 32 columns long
-                long tasks = (long)ntl * ks;
-                double eff = (double)tasks / (double)(((tasks + slots - 1) / slots) * slots);
-                double score = eff - 0.005 * ks;                              // fewer split-K partials when efficiency ties
-                if (score > best) { best = score; bk = ks; }
-            }
-            return bk;
-        };
-        // long K (>= 1024 columns per slice even when both slots of every CU are used): the partials are cheap next to the
-        // loop, fill both slots (n=500, V=300: 240 vs 262 us per Gram); otherwise one workgroup per CU
-        d.ksplit = best_split(2 * ncu * (d.gram_kg == 2 ? 1 : 0) + ncu * (d.gram_kg == 2 ? 0 : 1));
-        if (d.q / d.ksplit < 1024) d.ksplit = best_split(ncu);
         const char *ek = getenv("BNR_GRAM_KSPLIT");                           // experiments only
-        if (ek && atoi(ek) > 0) d.ksplit = atoi(ek);
+        int kchunk0 = 0;
+        if (gram_plan(d.n_pad, d.q, ncu, (ev && atoi(ev) == 4) ? 4 : 2, (ek && atoi(ek) > 0) ? atoi(ek) : 0, &d.gram_kg, &d.ksplit, &kchunk0))
+            { delete c; return fail(BNR_ERR_BAD_ARG, "the model matrix is too large for the Gram's K split (n_pad x q / 32 columns must stay below 2 GiB per K-group)"); }
     }
     int kchunk = round_up((d.q + d.ksplit - 1) / d.ksplit, 8 * d.gram_kg);
     d.q_pad = kchunk * d.ksplit;
@@ -337,7 +364,7 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
     d.o_gamma = o; o += d.q;
     o = round_up(o, 16);
     d.o_S = o; o += d.q;
-    o += (d.q_pad - d.q) + 64;      // zeros behind S that nothing ever writes: the Gram reads S by column index up to two batches past q_pad without a clamp (X is zero there)
+    o += (d.q_pad - d.q) + BNR_GRAM_PREFETCH_COLS;      // zeros behind S that nothing ever writes: the Gram reads S by column index up to BNR_GRAM_LOOKAHEAD batches past q_pad without a clamp (X is zero there)
     d.rowlen = round_up(o, 16);
     d.eta = hyper->eta; d.zeta = hyper->zeta; d.iota = hyper->iota;
     d.aDelta = hyper->aDelta; d.bDelta = hyper->bDelta; d.nu = hyper->nu;
@@ -369,7 +396,7 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
             HIPCHK(hipStreamSynchronize(c->x.stream));       // the (synchronous, legacy-stream) uploads below must find the zeros in place
             return BNR_OK;
         };
-        TRY(in_alloc((void **)&Xd, sizeof(double) * (size_t)d.n_pad * (d.q_pad + 64)));   // + 64 zero columns: the Gram prefetch may run 5 batches past a slice
+        TRY(in_alloc((void **)&Xd, sizeof(double) * (size_t)d.n_pad * (d.q_pad + BNR_GRAM_PREFETCH_COLS)));   // zero columns behind X: the Gram's prefetch distance (bnr_kernels.h)
         TRY(in_alloc((void **)&yd, sizeof(double) * d.n_pad));
         TRY(in_alloc((void **)&ek, sizeof(int) * d.q));
         TRY(in_alloc((void **)&el, sizeof(int) * d.q));
@@ -386,7 +413,7 @@ static int chain_build(const bnr_chain *donor, int32_t n, int32_t V, int32_t R, 
         unsigned char *X8 = nullptr;
         int *nb = nullptr;
         if (xs.dtype == BNR_U8 || xs.dtype == BNR_I32 || xs.dtype == BNR_I64) {
-            TRY(in_alloc((void **)&X8, (size_t)d.n_pad * (d.q_pad + 64)));
+            TRY(in_alloc((void **)&X8, (size_t)d.n_pad * (d.q_pad + BNR_GRAM_PREFETCH_COLS)));
             TRY(in_alloc((void **)&nb, sizeof(int)));
         }
         TRY(upload_x(c, xs, Xd, X8, nb));
@@ -675,20 +702,26 @@ static bool group_shares_x(const bnr_exec &x)
         if (x.cds_pin[i].X != x.cds_pin[0].X || x.cds_pin[i].X8 != x.cds_pin[0].X8) return false;
     return true;
 }
-static void launch_xpass(bnr_exec &x, int s, int which)
+// tail_mask != 0 (a sweep): Delta and M of the same sweep (bnr_tail_a, k_tail's bits 2 | 4 | 256) ride in the same launch, one extra workgroup per chain in front of the grid
+static size_t tail_a_bytes(const bnr_exec &x) { return bnr_tail_a_lds_doubles(x.shape->R) * sizeof(double); }
+static void launch_xpass(bnr_exec &x, int s, int which, int tail_mask = 0)
 {
     // by default only where X is large (>= 8 MB per chain): the point is the L2 traffic beside the panel steps; small problems are chains of
     // latencies, and there the per-chain kernel's many small workgroups finish sooner (n = 200, V = 50: 125.8 vs 139.4 us per sweep of 8 chains)
     const bool big_x = (size_t)x.shape->n_pad * x.shape->q * sizeof(double) >= ((size_t)8 << 20);
+    const size_t lds_a = tail_mask ? tail_a_bytes(x) : 0;
     if (which == 3 && (x.group_xpass == 1 || (x.group_xpass < 0 && big_x)) && group_shares_x(x) && 16 * (size_t)x.shape->chunk_x * sizeof(double) <= 48 * 1024) {
         // one workgroup per column chunk and row slice for all members: X comes out of the L2s once, not once per chain
         // long column chunks (large q: 177 columns per workgroup at config 5): the straight-line column loop -- config 5 x 8 chains, where the scalar branch is the longer
         // chain behind the Gram; at the headline shape (32 columns per workgroup) it brought nothing per sweep (notes S), so short chunks keep the first kernel
-        if (x.shape->chunk_x > 64) launch_late_xpass_group2(x, s);
-        else hipLaunchKernelGGL(k_xpass_group, dim3(x.shape->nblk_x * ((x.shape->n_pad + 255) / 256)), dim3(256), 16 * x.shape->chunk_x * sizeof(double), x.stream, bnr_many{x.cds}, s, x.nb);
+        const size_t lds = std::max(16 * x.shape->chunk_x * sizeof(double), lds_a);
+        const unsigned grid = (unsigned)(x.shape->nblk_x * ((x.shape->n_pad + 255) / 256) + (tail_mask ? x.nb : 0));
+        if (x.shape->chunk_x > 64) launch_late_xpass_group2(x, s, grid, lds, tail_mask);
+        else hipLaunchKernelGGL(k_xpass_group, dim3(grid), dim3(256), lds, x.stream, bnr_many{x.cds}, s, x.nb, tail_mask);
         return;
     }
-    BNR_LAUNCH(k_xpass, dim3(round_up(x.shape->nblk_x, 8) * x.nb), dim3(256), 3 * x.shape->chunk_x * sizeof(double), x.stream, x, s, which, x.nb);
+    const size_t lds = std::max(3 * x.shape->chunk_x * sizeof(double), lds_a);
+    BNR_LAUNCH(k_xpass, dim3(round_up(x.shape->nblk_x, 8) * x.nb + (tail_mask ? round_up(x.nb, 8) : 0)), dim3(256), lds, x.stream, x, s, which, x.nb, tail_mask);
 }
 // Which factorization: right-looking (k_chol_step behind k_gram_reduce: the trailing update spread over the whole chip) unless the
 // caller asks for the left-looking one (k_chol_ll: no reduction pass, ceil(nbk/4) + nbk - 1 workgroups per chain and launch, can
@@ -880,10 +913,11 @@ static void launch_backproj(bnr_exec &x, int s, int flags)
 static void launch_tail(bnr_exec &x, int s, int mask, int xg_src)
 {
     const size_t rv = (size_t)x.shape->R * x.shape->V;
-    if (rv <= BNR_TAIL_U_LDS) { BNR_LAUNCH(k_tail, dim3(1, 1, x.nb), dim3(BNR_TAIL_THREADS), rv * sizeof(double), x.stream, x, s, mask, xg_src); return; }
+    const size_t lds_a = (mask & BNR_TAIL_EARLY) ? tail_a_bytes(x) : 0;       // Delta / M / inv(M) asked for here (hooks, a loaded row): bnr_tail_a's work matrices behind u
+    if (rv <= BNR_TAIL_U_LDS) { BNR_LAUNCH(k_tail, dim3(1, 1, x.nb), dim3(BNR_TAIL_THREADS), rv * sizeof(double) + lds_a, x.stream, x, s, mask, xg_src); return; }
     // u beyond the LDS budget: the instantiation that reads it from the table row
-    if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tail<bnr_one, false>), dim3(1, 1, 1), dim3(BNR_TAIL_THREADS), 0, x.stream, bnr_one{*x.shape}, s, mask, xg_src);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tail<bnr_many, false>), dim3(1, 1, x.nb), dim3(BNR_TAIL_THREADS), 0, x.stream, bnr_many{x.cds}, s, mask, xg_src);
+    if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tail<bnr_one, false>), dim3(1, 1, 1), dim3(BNR_TAIL_THREADS), lds_a, x.stream, bnr_one{*x.shape}, s, mask, xg_src);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tail<bnr_many, false>), dim3(1, 1, x.nb), dim3(BNR_TAIL_THREADS), lds_a, x.stream, bnr_many{x.cds}, s, mask, xg_src);
 }
 // The scalar tail of sweep s with everything it needs: with split_sums the per-block partial sums of update_theta! / update_Lambda!
 // (gibbs.jl:476, 603-605) are not computed by the back-projection on the critical chain but by a launch of their own in front of the tail --
@@ -896,7 +930,7 @@ static bool split_sums(const bnr_exec &x) { return x.split_sums == 1 || (x.split
 static void launch_full_tail(bnr_exec &x, int s)
 {
     if (split_sums(x)) launch_backproj(x, s, 4);
-    launch_tail(x, s, 1023, 0);
+    launch_tail(x, s, 1023 & ~BNR_TAIL_EARLY, 0);           // (Delta, M, inv(M) of sweep s ran beside its X pass: launch_sweep)
 }
 static hipEvent_t next_event(bnr_exec &x)
 {
@@ -935,7 +969,7 @@ static void launch_sweep(bnr_exec &x, int s, bool prev_tail)
     }
     if (prev_tail) launch_full_tail(x, s - 1);
     launch_node(x, s, 3);
-    launch_xpass(x, s, 3);
+    launch_xpass(x, s, 3, BNR_TAIL_EARLY);
     launch_rhs(x, s);
     if (overlap) { for (hipEvent_t e : ej) if (e) HIPNOTE(hipStreamWaitEvent(x.stream, e, 0)); }
     else { launch_gram(x, s, sb, timed); launch_chol(x, s, sb); }
@@ -2219,10 +2253,13 @@ static int late_kernels_lds_attributes(int bytes)
 {
     const void *late[] = {(const void *)&k_xpass_group2<0>, (const void *)&k_backproj64<bnr_one>, (const void *)&k_backproj64<bnr_many>};
     for (const void *f : late) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    // k_tail outside a sweep (hooks, a loaded row): u (up to BNR_TAIL_U_LDS doubles) and the R x R work matrices of update_M! side by side
+    const void *tails[] = {(const void *)&k_tail<bnr_one>, (const void *)&k_tail<bnr_many>, (const void *)&k_tail<bnr_one, false>, (const void *)&k_tail<bnr_many, false>};
+    for (const void *f : tails) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     return BNR_OK;
 }
-static void launch_late_xpass_group2(bnr_exec &x, int s)
-{ hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xpass_group2<0>), dim3(x.shape->nblk_x * ((x.shape->n_pad + 255) / 256)), dim3(256), 16 * x.shape->chunk_x * sizeof(double), x.stream, bnr_many{x.cds}, s, x.nb); }
+static void launch_late_xpass_group2(bnr_exec &x, int s, unsigned grid, size_t lds, int tail_mask)
+{ hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xpass_group2<0>), dim3(grid), dim3(256), lds, x.stream, bnr_many{x.cds}, s, x.nb, tail_mask); }
 static void launch_late_backproj64(bnr_exec &x, int s, int flags, size_t lds64)
 { BNR_LAUNCH(k_backproj64, dim3(round_up((x.shape->nblk_bp + 1) / 2, 8) * x.nb), dim3(256), lds64, x.stream, x, s, flags, x.nb); }
 }

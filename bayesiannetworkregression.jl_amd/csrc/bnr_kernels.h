@@ -437,6 +437,173 @@ __global__ __launch_bounds__(64) void k_node(const SRC chain_src, int s, int mod
 #endif
 }
 
+// in-place lower Cholesky of an LDS matrix by ONE wavefront (all 64 lanes call); returns 0 ok / 1 not positive definite
+__device__ inline int wave_chol(double *A, int R, int lane)
+{
+    for (int j = 0; j < R; ++j) {
+        bnr_wsync();
+        double d = A[j + R * j];
+        if (!(d > 0.0) || !isfinite(d)) return 1;
+        d = sqrt(d);
+        bnr_wsync();
+        for (int i = j + lane; i < R; i += 64) A[i + R * j] = (i == j) ? d : A[i + R * j] / d;
+        bnr_wsync();
+        int m = R - j - 1;
+        for (int idx = lane; idx < m * m; idx += 64) {
+            int c = j + 1 + idx / m, i = j + 1 + idx % m;
+            if (i >= c) A[i + R * c] = A[i + R * c] - A[i + R * j] * A[c + R * j];
+        }
+    }
+    bnr_wsync();
+    return 0;
+}
+// T = inverse of the lower-triangular LDS matrix A (column j by lane j; R <= 32)
+__device__ inline void wave_tri_inverse(const double *A, double *T, int R, int lane)
+{
+    if (lane < R) {
+        const int j = lane;
+        for (int i = 0; i < R; ++i) {
+            double v = 0.0;
+            if (i == j) v = 1.0 / A[j + R * j];
+            else if (i > j) {
+                double sacc = 0.0;
+                for (int k = j; k < i; ++k) sacc += A[i + R * k] * T[k + R * j];
+                v = -sacc / A[i + R * i];
+            }
+            T[i + R * j] = v;
+        }
+    }
+    bnr_wsync();
+}
+
+
+// ===================================================================================== the early part of the scalar tail: Delta and M (gibbs.jl:496-499, 516-548)
+// update_Delta! needs xi, update_M! needs u and xi: both are k_node's output of THIS sweep, not the back-projection's.  Round 6: in a sweep they no longer wait
+// for the back-projection in k_tail (one workgroup per chain on the scalar branch, 32 us alone / 58 us beside the Gram's drain, of which this part is 20) but run as ONE
+// extra workgroup per chain inside the launch of the X pass that follows k_node (k_xpass / k_xpass_group / k_xpass_group2, tail_mask != 0: the first workgroups of the
+// grid), i.e. beside it, off every chain of dependencies -- the draws are keyed by (iteration, site, element), so when they are evaluated changes nothing.
+// The same function serves k_tail (the hooks bnr_update_Delta / bnr_update_M, and inv(M) / logdet M for a row that was loaded or initialised).
+//   mask bits: 2 Delta, 4 M, 256 inv(M) and logdet M for the next k_node (cd.Minv).
+//   Called by EVERY thread of a workgroup of >= 256 threads (block barriers inside); threads 256.. only take part in the barriers.
+//   lds: 4 R^2 + 8 doubles.
+#define BNR_TAIL_EARLY (2 | 4 | 256)
+__host__ __device__ inline size_t bnr_tail_a_lds_doubles(int R) { return (size_t)4 * R * R + 8; }
+__device__ __forceinline__ void bnr_tail_a(const bnr_dev &cd, const bnr_plan_entry P, int mask, double *lds, int tid)
+{
+    const int R = cd.R, V = cd.V, RR = R * R;
+    double *sPsi = lds, *sA = lds + RR, *sT = lds + 2 * RR, *sBm = lds + 3 * RR, *sredA = lds + 4 * RR;     // sredA: 2 x 4 wave partials
+    const bool act = tid < 256;
+    const int wave = bnr_sgpr(tid >> 6), lane = tid & 63;
+    double *row = bnr_sgpr_global(cd.trace + (size_t)P.row * cd.rowlen);
+    const double *su_row = row + cd.o_u;
+    int cap = 0;
+    // sum xi, #nonzero xi (sums of zeros and ones: exact whatever the order)
+    if (act && (mask & (2 | 4))) {
+        double sxi = 0.0, snz = 0.0;
+        for (int v = tid; v < V; v += 256) { double x = row[cd.o_xi + v]; sxi += x; snz += (!(fabs(x) <= 0.1)) ? 1.0 : 0.0; }
+        sxi = wave_sum(sxi); snz = wave_sum(snz);
+        if (lane == 0) { sredA[wave] = sxi; sredA[4 + wave] = snz; }
+    }
+    // Psi = I + sum_v u_v u_v' (gibbs.jl:516-525), sequential over v per entry (the reference's order); u from the table row (k_node has just written it)
+    if (act && (mask & 4)) {
+        for (int idx = tid; idx < RR; idx += 256) {
+            const int a = idx % R, b = idx / R;
+            double sacc = (a == b) ? 1.0 : 0.0;
+            int v = 0;
+            for (; v + 3 < V; v += 4) {                 // four nodes' loads in flight, the terms added one after the other in the order of v
+                const double a0 = su_row[a + R * v], b0 = su_row[b + R * v], a1 = su_row[a + R * (v + 1)], b1 = su_row[b + R * (v + 1)];
+                const double a2 = su_row[a + R * (v + 2)], b2 = su_row[b + R * (v + 2)], a3 = su_row[a + R * (v + 3)], b3 = su_row[b + R * (v + 3)];
+                sacc += a0 * b0; sacc += a1 * b1; sacc += a2 * b2; sacc += a3 * b3;
+            }
+            for (; v < V; ++v) sacc += su_row[a + R * v] * su_row[b + R * v];
+            sPsi[idx] = sacc;
+            sA[idx] = sacc;
+        }
+    }
+    __syncthreads();
+    double sxi = 0.0, snz = 0.0;
+    if (mask & (2 | 4)) for (int w = 0; w < 4; ++w) { sxi += sredA[w]; snz += sredA[4 + w]; }
+    sxi = bnr_sgpr_f64(sxi); snz = bnr_sgpr_f64(snz);
+    const double df = cd.nu + snz;
+    // independent work on separate wavefronts
+    if (act && wave == 0 && (mask & 2)) {                                        // Delta (gibbs.jl:496-499, 130-140)
+        double a = cd.aDelta + sxi, b = cd.bDelta + ((double)V - sxi);
+        double g = 0.0;
+        if (a > 0.0 && b > 0.0 && lane < 2) g = bnr_gamma(cd.seed, lane == 0 ? a : b, P.it, SITE_DELTA, (uint32_t)lane, &cap);
+        double g1 = bnr_readlane_c(g, 0), g2 = bnr_readlane_c(g, 1);
+        if (lane == 0) {
+            double out;
+            if (a > 0.0 && b > 0.0) out = g1 / (g1 + g2);
+            else if (a > 0.0) out = 1.0;
+            else if (b > 0.0) out = 0.0;
+            else { double ua, ub; bnr_draw2(cd.seed, P.it, SITE_DELTA_COIN, 0, 0, ua, ub); out = (ua < 0.5) ? 0.0 : 1.0; }
+            row[ROW_DELTA] = out;
+        }
+    }
+    if (act && wave == 1 && (mask & 4)) {                                        // Bartlett diagonal: chi-square draws
+        for (int j = lane; j < R; j += 64) sBm[j + R * j] = sqrt(2.0 * bnr_gamma(cd.seed, 0.5 * (df - j), P.it, SITE_M_CHI, (uint32_t)j, &cap));
+    }
+    if (act && wave == 2 && (mask & 4)) {                                        // Bartlett strictly lower: normals; upper: 0
+#pragma unroll 1
+        for (int idx = lane; idx < RR; idx += 64) {
+            int i = idx % R, j = idx / R;
+            if (i > j) sBm[idx] = bnr_normal(cd.seed, P.it, SITE_M_N, (uint32_t)(i * R + j), 0);
+            else if (i < j) sBm[idx] = 0.0;
+        }
+    }
+    if (act && wave == 3 && (mask & 4)) {                                        // C = chol(Psi), retry ladder gibbs.jl:529-543
+        int f = wave_chol(sA, R, lane);
+        if (f) {
+            if (lane == 0) atomicAdd((unsigned long long *)&cd.counters[0], 1ull);
+            for (int idx = lane; idx < RR; idx += 64) sA[idx] = sPsi[idx] + ((idx % R == idx / R) ? 1e-5 : 0.0);
+            f = wave_chol(sA, R, lane);
+            if (f && lane == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[5], 1ull); }
+        }
+        for (int idx = lane; idx < RR; idx += 64) { int a = idx % R, b = idx / R; if (a < b) sA[idx] = 0.0; }
+    }
+    __syncthreads();
+    // wavefront 0, wave-level sync: M ~ InverseWishart(df, Psi) = (C A^-T)(C A^-T)', then inv(M), logdet M
+    if (act && wave == 0 && (mask & (4 | 256))) {
+        if (mask & 4) {
+            wave_tri_inverse(sBm, sT, R, lane);                                   // T = A^-1
+            for (int idx = lane; idx < RR; idx += 64) {                           // B = C T' -> sPsi
+                int a = idx % R, b = idx / R;
+                double sacc = 0.0;
+                for (int k = 0; k < R; ++k) sacc += sA[a + R * k] * sT[b + R * k];
+                sPsi[idx] = sacc;
+            }
+            bnr_wsync();
+            for (int idx = lane; idx < RR; idx += 64) {                           // M = B B'
+                int a = idx % R, b = idx / R;
+                double sacc = 0.0;
+                for (int k = 0; k < R; ++k) sacc += sPsi[a + R * k] * sPsi[b + R * k];
+                row[cd.o_M + idx] = sacc;
+                sBm[idx] = sacc;
+            }
+        } else {
+            for (int idx = lane; idx < RR; idx += 64) sBm[idx] = row[cd.o_M + idx];
+        }
+        bnr_wsync();
+        if (mask & 256) {
+            // inv(M) = Lm^-T Lm^-1 with Lm = chol(M) (gibbs.jl:315 computes inv(M); same matrix, triangular-inverse route)
+            for (int idx = lane; idx < RR; idx += 64) sA[idx] = sBm[idx];
+            int f = wave_chol(sA, R, lane);
+            if (f && lane == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[6], 1ull); }
+            double ldm = 0.0;
+            for (int i = 0; i < R; ++i) ldm += 2.0 * log(sA[i + R * i]);
+            wave_tri_inverse(sA, sT, R, lane);                                    // Linv (lower)
+            for (int idx = lane; idx < RR; idx += 64) {
+                int a = idx % R, b = idx / R, k0 = a > b ? a : b;
+                double sacc = 0.0;
+                for (int k = k0; k < R; ++k) sacc += sT[k + R * a] * sT[k + R * b];
+                cd.Minv[idx] = sacc;
+            }
+            if (lane == 0) cd.Minv[RR] = ldm;
+        }
+    }
+    if (cap) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
+}
+
 // ===================================================================================== k_xpass
 // One pass over X.  grid = nblk_x blocks of 256 threads; block b owns columns [b*chunk, (b+1)*chunk).
 //   W_e  = lowtri(u_new' diag(lam_prev) u_new)_e               (gibbs.jl:421)           -> Wbuf
@@ -444,16 +611,26 @@ __global__ __launch_bounds__(64) void k_node(const SRC chain_src, int s, int mod
 //   PW[b][i] = sum_{e in chunk} X[i,e] W_e ;  PA[b][i] = sum X[i,e] sz_e                 (gibbs.jl:432-433)
 // which: bit0 -> W/PW, bit1 -> sz/PA, bit2 -> PG = partial X*gamma(row `P.prev` if bit3 else row P.row)
 template <class SRC>
-__global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int which, int nchains)
+__global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int which, int nchains, int tail_mask)
 {
-    // 1-D grid = round_up(blocks, 8) x chains, decoded like k_gram / k_backproj (chains that read the same columns of X
-    // are neighbours on one XCD)
-    const int gid = blockIdx.x, gx = gid & 7, gr = gid >> 3;
+    // 1-D grid = [round_up(chains, 8) when tail_mask != 0] + round_up(blocks, 8) x chains, decoded like k_gram / k_backproj (chains that read
+    // the same columns of X are neighbours on one XCD)
+    extern __shared__ double sh[];
+    int gid = blockIdx.x;
+    if (tail_mask) {
+        // the first workgroups of the grid: Delta and M of this sweep, one workgroup per chain, beside the pass (bnr_tail_a)
+        const int nfront = (nchains + 7) & ~7;
+        if (gid < nfront) {
+            if (gid < nchains) { const bnr_dev &ct = chain_src.at(gid); bnr_tail_a(ct, ct.plan[ct.pbase[0] + s], tail_mask, sh, threadIdx.x); }
+            return;
+        }
+        gid -= nfront;
+    }
+    const int gx = gid & 7, gr = gid >> 3;
     const int bid = (gr / nchains) * 8 + gx;
     const bnr_dev &cd = chain_src.at(gr % nchains);
     if (bid >= cd.nblk_x) return;
     if (BNR_EXP_SKIP_SCALAR() && which == 3) return;
-    extern __shared__ double sh[];
     double *sW = sh, *sZ = sh + cd.chunk_x, *sG = sh + 2 * cd.chunk_x;
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     const double *row = cd.trace + (size_t)P.row * cd.rowlen;
@@ -501,14 +678,19 @@ __global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int w
 // bytes from the L2s, and the factorization's panel steps that run beside this kernel keep their memory latency (a dependent launch
 // beside a streaming kernel: 21 us instead of 6.6, tools/interfere_probe.hip).  which = 3 only (W and sqrt(S) z1).
 //   grid = nblk_x x ceil(n_pad / 256), 256 threads, dynamic LDS = 2 x 8 x chunk_x doubles.
-__global__ __launch_bounds__(256) void k_xpass_group(const bnr_many chain_src, int s, int nchains)
+__global__ __launch_bounds__(256) void k_xpass_group(const bnr_many chain_src, int s, int nchains, int tail_mask)
 {
     if (BNR_EXP_SKIP_SCALAR()) return;
+    extern __shared__ double sh[];
+    int wg = blockIdx.x;
+    if (tail_mask) {                                       // the first nchains workgroups: Delta and M of this sweep beside the pass (bnr_tail_a)
+        if (wg < nchains) { const bnr_dev &ct = chain_src.at(wg); bnr_tail_a(ct, ct.plan[ct.pbase[0] + s], tail_mask, sh, threadIdx.x); return; }
+        wg -= nchains;
+    }
     const bnr_dev &c0 = chain_src.at(0);                  // the geometry and the shared X, index maps
-    const int rs = (c0.n_pad + 255) / 256, bid = blockIdx.x / rs, slice = blockIdx.x % rs, tid = threadIdx.x;
+    const int rs = (c0.n_pad + 255) / 256, bid = wg / rs, slice = wg % rs, tid = threadIdx.x;
     const int chunk = c0.chunk_x, e0 = bid * chunk, ne = min(chunk, c0.q - e0), R = c0.R;
     const size_t ld = c0.n_pad;
-    extern __shared__ double sh[];
     double *sW = sh, *sZ = sh + 8 * chunk;                 // [chain][column of the chunk]
     __shared__ double *s_pw[8], *s_pa[8];
     const int i = slice * 256 + tid;
@@ -561,9 +743,10 @@ __global__ __launch_bounds__(256) void k_xpass_group(const bnr_many chain_src, i
 // C[m][n]: lane l holds rows m = (l>>4) + 4*reg, column n = l&15.
 // Here m indexes the tile's COLUMN (j) and n its ROW (i): A = X[j-rows], B = S_e X[i-rows], so that a lane's results are
 // consecutive in i and the tile is written column-major (i fastest) with coalesced 128-byte segments.
-// Workgroup = 1024 threads = 16 waves on one 64x64 tile of the LOWER triangle: 4 K-groups x (2x2 waves of 32x32).
-// Measured issue rate of the f64 MFMA rises with waves per SIMD (1 wave: 139, 2: 103, 4: 92 cycles/MFMA;
-// profiles/round1_mfma_f64_peak.txt), hence 4 waves per SIMD and the in-workgroup K split, reduced through LDS.
+// Workgroup = KG x 256 threads on one 64x64 tile of the LOWER triangle: KG K-groups x (2x2 waves of 32x32), the K-groups reduced through LDS.
+// The f64 MFMA pipe issues one v_mfma_f64_16x16x4_f64 per 64 cycles per SIMD from a single wave (profiles/round5_mfma_f64_peak.txt); several
+// waves per SIMD are there to hide the loop's staging work (global -> LDS -> fragments) and its barrier, not to raise the issue rate
+// (the round-1 figures that once stood here, "139 / 103 / 92 cycles per MFMA at 1 / 2 / 4 waves", were a microbenchmark artefact).
 // blockIdx.y = K slice across workgroups (split-K partials, summed by k_gram_reduce).
 typedef double bnr_d4 __attribute__((ext_vector_type(4)));
 typedef double bnr_d2 __attribute__((ext_vector_type(2)));
@@ -592,6 +775,20 @@ __device__ __forceinline__ void bnr_gram_count(const bnr_dev &cd, int tj)
     (void)cd; (void)tj;
 }
 #define BNR_GRAM_KB 16                // columns of X per staged batch (4 MFMA k-steps): one barrier per 16 MFMAs of a wave
+// The Gram loops issue the loads of batch b + 2 while batch b is computed and never clamp: the last trips of a K-group read up to
+// BNR_GRAM_LOOKAHEAD batches past its slice -- the next slice's columns, or past q_pad.  Both X (columns) and every trace row behind S
+// (entries) are therefore followed by BNR_GRAM_PREFETCH_COLS zeros that nothing ever writes (bnr_chain_create); what is loaded there is
+// stored to LDS and never used by a compute step, but it must be addressable and finite-times-zero must stay out of the sums.
+#define BNR_GRAM_LOOKAHEAD 2
+#define BNR_GRAM_PREFETCH_COLS 64
+static_assert((BNR_GRAM_LOOKAHEAD + 1) * BNR_GRAM_KB <= BNR_GRAM_PREFETCH_COLS, "zero padding behind X and S must cover the Gram loops' prefetch distance (a half batch + two whole ones)");
+// Span in bytes that ONE K-group's buffer resource must address (base = first column of its slice): its columns, the prefetch
+// distance and the per-lane offset (at most 16 columns of n_pad rows).  The resource is a 2 GiB window with 32-bit scalar offsets:
+// the host raises the K split until this fits (bnr_host_gram_plan; ADVICE r5: n = 14 000 with V >= 280 used to overflow silently).
+__host__ __device__ inline long long bnr_gram_span_bytes(int n_pad, int kchunk, int kg)
+{
+    return ((long long)(kchunk / kg) + BNR_GRAM_PREFETCH_COLS + 16) * (long long)n_pad * 8;
+}
 #ifndef BNR_GRAM_SKIP_DEAD
 #define BNR_GRAM_SKIP_DEAD 1          // 1: what lies above the diagonal is not computed where whole waves or whole MFMAs can be left out: the upper 32 x 32
                                       // block of a diagonal tile (its two waves only stage: 5.6 % of the launch's MFMAs at ntile = 8; 8 chains 216.5 ->
@@ -659,7 +856,7 @@ __device__ __forceinline__ void bnr_gram16_task(const bnr_gram_geom &cd, const d
     const unsigned offI = 8u * ((unsigned)(ti * BNR_GT + 2 * rp) + (unsigned)c * (unsigned)ld), offJ = 8u * ((unsigned)(tj * BNR_GT + 2 * rp) + (unsigned)c * (unsigned)ld);
     const unsigned off8 = 8u * 8u * (unsigned)ld, offS = 8u * (unsigned)c;
     const double *xb = bnr_sgpr_global(cd.X + (size_t)eb * ld);        // uniform: first column of this K-group, pinned to scalar registers (see bnr_gram8_task)
-    const double *sb = bnr_sgpr_global(Sp + eb);                       // uniform; S is followed by q_pad - q + 64 zeros in every trace row: no clamp
+    const double *sb = bnr_sgpr_global(Sp + eb);                       // uniform; S is followed by q_pad - q + BNR_GRAM_PREFETCH_COLS zeros in every trace row: no clamp
     const int PANEL = BNR_GRAM_KB * BNR_GT;                            // doubles per panel (16 columns x 64 rows)
     double *stg = sred + (size_t)kg * (4 * PANEL);                     // [buf][I|J][col][row ^ swizzle]
     const int woff = c * BNR_GT + ((2 * rp) ^ ((c & 1) << 4));         // columns c and c + 8 have the same parity
@@ -704,7 +901,7 @@ __device__ __forceinline__ void bnr_gram16_task(const bnr_gram_geom &cd, const d
         }                                                                                                 \
     } while (0)
     // batches past the end of the slice read the following columns or the zero-padded tail of X (the host allocates
-    // q_pad + 64 columns); they are stored but never used by a compute step
+    // q_pad + BNR_GRAM_PREFETCH_COLS columns); they are stored but never used by a compute step
     BNR_GRAM_LOAD(0);
     BNR_GRAM_STORE(0);
     BNR_GRAM_LOAD(1);
@@ -784,9 +981,10 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
 }
 
 // k_gram8: the same Gram, the same task map, the same summation order per element (bitwise the same partial tiles) -- for SIX
-// wavefronts per SIMD.  The issue rate of v_mfma_f64_16x16x4_f64 on a SIMD depends on how many waves feed it, not on how many
-// independent accumulators a wave has (profiles/round1_mfma_f64_peak.txt: 1 wave 139-180 cycles per MFMA whatever NACC, 2 waves 103,
-// 4 waves 92, 8 waves 71; 64 = spec).  Three 512-thread workgroups per CU = 6 waves per SIMD: __launch_bounds__(512, 6) -- the second
+// wavefronts per SIMD.  What the extra waves buy is cover for the loop's staging and VALU work and for its barrier per batch (every VALU
+// instruction issued between f64 MFMAs takes 6-14 cycles from the matrix pipe, tools/mfma_f64_mix.hip; the pipe itself issues at the spec
+// rate of 64 cycles per MFMA from ONE wave -- the round-1 "issue rate grows with the waves per SIMD" was a microbenchmark artefact,
+// profiles/round5_mfma_f64_peak.txt).  Three 512-thread workgroups per CU = 6 waves per SIMD: __launch_bounds__(512, 6) -- the second
 // argument is the minimum number of WAVES PER SIMD, not of blocks per CU -- caps the kernel at 80 VGPRs (74 used, no spills), and
 // batches of 8 columns keep a workgroup at 32 KiB of LDS (half the staging registers and half the image of k_gram's 16:
 // 2 K-groups x 2 buffers x [I | J] x 8 x 64 doubles; a barrier per 8 MFMAs of a wave), with a K-group reduction that needs one tile
@@ -820,7 +1018,7 @@ __device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const do
     // address VALU at all (round 5, tools/mfma_f64_mix.hip: every VALU instruction issued between f64 MFMAs takes 6-14 cycles from the
     // matrix pipe, LDS / VMEM / SALU instructions and barriers take none; the loop used to carry 15 VALU instructions per 8 MFMAs)
     const double *xb = bnr_sgpr_global(cd.X + (size_t)eb * ld);
-    const double *sb = bnr_sgpr_global(Sp + eb);       // S is followed by q_pad - q + 32 zeros in every trace row (bnr_chain_create): no clamp; X is zero there
+    const double *sb = bnr_sgpr_global(Sp + eb);       // S is followed by q_pad - q + BNR_GRAM_PREFETCH_COLS zeros in every trace row (bnr_chain_create): no clamp; X is zero there
     constexpr int PANEL = KB * BNR_GT;                 // doubles per panel (8 columns x 64 rows)
     double *stg = sred + (size_t)kg * (4 * PANEL);     // [buf][I|J][col][row ^ swizzle]
     const int woff = c * BNR_GT + ((2 * rp) ^ ((c & 1) << 4));
@@ -854,7 +1052,7 @@ __device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const do
         if (!(DIAG)) c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);        \
         c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);                     \
     } while (0)
-    // batches past the end of the slice read the following columns or the zero-padded tail of X (q_pad + 64 columns are
+    // batches past the end of the slice read the following columns or the zero-padded tail of X (q_pad + BNR_GRAM_PREFETCH_COLS columns are
     // allocated); they are stored but never used by a compute step
     BNR_G8_LOAD(0);
     BNR_G8_STORE(0);
@@ -2148,51 +2346,13 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
 }
 
 // ===================================================================================== k_tail
-// One block of 1024 threads.  mask bits: 1 theta, 2 Delta, 4 M, 8 mu, 16 Lambda, 32 pi, 64 carried sums (rr, sig_q for
+// One block of BNR_TAIL_THREADS threads per chain.  mask bits: 1 theta, 2 Delta, 4 M, 8 mu, 16 Lambda, 32 pi, 64 carried sums (rr, sig_q for
 // the next tau2), 128 ring wrap copy, 256 inv(M)/logdet M for the next k_node, 512 pre-draw the next tau2.
 // When a bit is clear the value already in `row` is kept.
 // xg_src: 0 = cd.xg (from k_solve_gemv); 1 = sum of the PG partials (X*gamma by k_xpass bit2).
-// Independent scalar draws sit on different wavefronts so that their long scalar sampler code runs concurrently; the
-// small R x R matrix work runs on single wavefronts with wave-level synchronisation only (no block barriers).
-
-// in-place lower Cholesky of an LDS matrix by ONE wavefront (all 64 lanes call); returns 0 ok / 1 not positive definite
-__device__ inline int wave_chol(double *A, int R, int lane)
-{
-    for (int j = 0; j < R; ++j) {
-        bnr_wsync();
-        double d = A[j + R * j];
-        if (!(d > 0.0) || !isfinite(d)) return 1;
-        d = sqrt(d);
-        bnr_wsync();
-        for (int i = j + lane; i < R; i += 64) A[i + R * j] = (i == j) ? d : A[i + R * j] / d;
-        bnr_wsync();
-        int m = R - j - 1;
-        for (int idx = lane; idx < m * m; idx += 64) {
-            int c = j + 1 + idx / m, i = j + 1 + idx % m;
-            if (i >= c) A[i + R * c] = A[i + R * c] - A[i + R * j] * A[c + R * j];
-        }
-    }
-    bnr_wsync();
-    return 0;
-}
-// T = inverse of the lower-triangular LDS matrix A (column j by lane j; R <= 32)
-__device__ inline void wave_tri_inverse(const double *A, double *T, int R, int lane)
-{
-    if (lane < R) {
-        const int j = lane;
-        for (int i = 0; i < R; ++i) {
-            double v = 0.0;
-            if (i == j) v = 1.0 / A[j + R * j];
-            else if (i > j) {
-                double sacc = 0.0;
-                for (int k = j; k < i; ++k) sacc += A[i + R * k] * T[k + R * j];
-                v = -sacc / A[i + R * i];
-            }
-            T[i + R * j] = v;
-        }
-    }
-    bnr_wsync();
-}
+// Independent scalar draws sit on different wavefronts so that their long scalar sampler code runs concurrently.
+// Round 6: in a sweep this kernel runs with the bits 1 | 8 | 16 | 32 | 64 | 128 | 512 only -- what needs the back-projection's output; Delta, M and inv(M) (bits 2, 4, 256:
+// bnr_tail_a above) have been computed beside the X pass of the same sweep by then.  With those bits set (the hooks, a loaded or initialised row) bnr_tail_a runs here first.
 
 #define BNR_TAIL_U_LDS 15360     // doubles of u (R x V) that k_tail stages in LDS (120 KB); a larger u is read from the trace row (same values, same order of operations)
 #define BNR_TAIL_THREADS 512   // 8 wavefronts: the seven role waves of phase 3 + one; two per SIMD, so the kernel may use 256 vector registers (no spills: with
@@ -2207,9 +2367,8 @@ template <class SRC, bool ULDS = true>
 __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, int s, int mask, int xg_src)
 {
     const bnr_dev &cd = chain_src.get();
-    extern __shared__ double su_lds[];           // R x V: u of this row (staged once, used by Psi and by the q pass) -- where it fits the LDS budget (BNR_TAIL_U_LDS), else read from the row
+    extern __shared__ double su_lds[];           // R x V: u of this row (staged once for the q pass) -- where it fits the LDS budget (BNR_TAIL_U_LDS), else read from the row --, then bnr_tail_a's 4 R^2 + 8 doubles
     __shared__ double sred[3 * 16];
-    __shared__ double sPsi[BNR_RMAX * BNR_RMAX], sA[BNR_RMAX * BNR_RMAX], sT[BNR_RMAX * BNR_RMAX], sBm[BNR_RMAX * BNR_RMAX];
     __shared__ double sll[3 * BNR_RMAX + 1], slam[BNR_RMAX], spi[3 * BNR_RMAX];
     __shared__ double sval[8];
     __shared__ int sflag[2];
@@ -2229,6 +2388,11 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
 #define BNR_TSTAMP(slot) do { } while (0)
 #endif
     BNR_TSTAMP(0);
+    if (mask & BNR_TAIL_EARLY) {                   // Delta, M, inv(M): only outside a sweep (hooks, refresh) -- in a sweep the X pass's launch has done them
+        bnr_tail_a(cd, P, mask, su_lds + (ULDS ? (size_t)R * V : 0), tid);
+        if (!(mask & ~BNR_TAIL_EARLY)) return;
+        __syncthreads();
+    }
     if (tid < R) slam[tid] = row[cd.o_lam + tid];
     if (tid == 0) { sval[1] = row[ROW_MU]; sflag[0] = 0; sflag[1] = 0; }
     constexpr bool u_lds = ULDS;
@@ -2262,70 +2426,51 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
     }
     __syncthreads();
     BNR_TSTAMP(1);
-    // sum xi, #nonzero xi, sum (y - X gamma): one three-way block reduction
-    double sxi = 0.0, snz = 0.0, sres = 0.0;
-    if (mask & (2 | 4)) for (int v = tid; v < V; v += blockDim.x) { double x = row[cd.o_xi + v]; sxi += x; snz += (!(fabs(x) <= 0.1)) ? 1.0 : 0.0; }
-    if (mask & 8) for (int i = tid; i < n; i += blockDim.x) sres += cd.y[i] - cd.xg[i];
-    if (mask & (2 | 4 | 8)) {
-        sxi = wave_sum(sxi); snz = wave_sum(snz); sres = wave_sum(sres);
-        if (lane == 0) { sred[wave] = sxi; sred[16 + wave] = snz; sred[32 + wave] = sres; }
-    }
-    // ---- phase 2: Psi = I + sum_v u_v u_v' (gibbs.jl:516-525), sequential over v per entry (the reference's order)
-    if (mask & 4) {
-        for (int idx = tid; idx < R * R; idx += blockDim.x) {
-            int a = idx % R, b = idx / R;
-            double sacc = (a == b) ? 1.0 : 0.0;
-            if (u_lds) for (int v = 0; v < V; ++v) sacc += su_lds[a + R * v] * su_lds[b + R * v];
-            else for (int v = 0; v < V; ++v) sacc += su_row[a + R * v] * su_row[b + R * v];
-            sPsi[idx] = sacc;
-            sA[idx] = sacc;
-        }
+    // sum (y - X gamma): block reduction (per-thread partial sums stride by the thread count, then the waves in order)
+    double sres = 0.0;
+    if (mask & 8) {
+        for (int i = tid; i < n; i += blockDim.x) sres += cd.y[i] - cd.xg[i];
+        sres = wave_sum(sres);
+        if (lane == 0) sred[32 + wave] = sres;
     }
     __syncthreads();
-    if (mask & (2 | 4 | 8)) {
-        sxi = 0.0; snz = 0.0; sres = 0.0;
-        for (int w = 0; w < nw; ++w) { sxi += sred[w]; snz += sred[16 + w]; sres += sred[32 + w]; }
-    }
+    if (mask & 8) { sres = 0.0; for (int w = 0; w < nw; ++w) sres += sred[32 + w]; }
     // (the same in every lane from here on: scalar registers -- the samplers inlined below need the vector ones)
-    sxi = bnr_sgpr_f64(sxi); snz = bnr_sgpr_f64(snz); sres = bnr_sgpr_f64(sres);
-    const double df = cd.nu + snz;
+    sres = bnr_sgpr_f64(sres);
     BNR_TSTAMP(2);
-    // ---- phase 3: independent work on separate wavefronts
-    if (wave == 0 && lane == 0 && (mask & 1)) {                                  // theta (gibbs.jl:476-479)
-        double g = bnr_gamma(cd.seed, cd.zeta + (V * (V + 1)) / 2.0, P.it, SITE_THETA, 0, &cap);
-        row[ROW_THETA] = g * (2.0 / (2.0 * cd.iota + sll[0]));
+    // ---- phase 3 (round 6): two chains of work side by side, no block barrier between the draws and the pass over the edges.
+    //   every wavefront: mu (one normal) and lambda (R categorical draws) evaluated REDUNDANTLY -- the same counters, the same values in every wave -- so that
+    //     the pass over the edges for the next tau2's sums, which needs both, starts without waiting for anybody (wave 0 writes them to the row);
+    //   wavefront 0:     the Gamma variates of theta (lane 0) and of the NEXT tau2 (lane 1: it does not depend on the sums it will scale) in one
+    //     divergence-free call, then pi;
+    //   wavefronts 1..7: rr and sig_q (the partition of rows and edges over 448 threads is what rounds 4-5 had: the same sums bit for bit).
+    double mu = sval[1];
+    if (mask & 8) {                                                               // mu (gibbs.jl:565-570)
+        mu = sres / n + sqrt(tau2 / n) * bnr_normal(cd.seed, P.it, SITE_MU, 0, 0);
+        if (tid == 0) row[ROW_MU] = mu;
     }
-    if (wave == 1 && (mask & 2)) {                                               // Delta (gibbs.jl:496-499, 130-140)
-        double a = cd.aDelta + sxi, b = cd.bDelta + ((double)V - sxi);
-        double g = 0.0;
-        if (a > 0.0 && b > 0.0 && lane < 2) g = bnr_gamma(cd.seed, lane == 0 ? a : b, P.it, SITE_DELTA, (uint32_t)lane, &cap);
-        double g1 = bnr_readlane_c(g, 0), g2 = bnr_readlane_c(g, 1);
-        if (lane == 0) {
-            double out;
-            if (a > 0.0 && b > 0.0) out = g1 / (g1 + g2);
-            else if (a > 0.0) out = 1.0;
-            else if (b > 0.0) out = 0.0;
-            else { double ua, ub; bnr_draw2(cd.seed, P.it, SITE_DELTA_COIN, 0, 0, ua, ub); out = (ua < 0.5) ? 0.0 : 1.0; }
-            row[ROW_DELTA] = out;
+    if ((mask & 16) && lane < R) {                                                // Lambda (gibbs.jl:586-636)
+        int r = lane;
+        double l0 = sll[1 + 3 * r], l1 = sll[2 + 3 * r], l2 = sll[3 + 3 * r];
+        double pmax = fmax(l0, fmax(l1, l2));
+        double w0 = prev[cd.o_pi + r] * exp(l0 - pmax), w1 = prev[cd.o_pi + r + R] * exp(l1 - pmax), w2 = prev[cd.o_pi + r + 2 * R] * exp(l2 - pmax);
+        double ua, ub;
+        bnr_draw2(cd.seed, P.it, SITE_LAMBDA, (uint32_t)r, 0, ua, ub);
+        double lv = bnr_lambda_value(bnr_categorical3(w0, w1, w2, ua));
+        slam[r] = lv;                                                             // (every wave stores the same values)
+        if (wave == 0) row[cd.o_lam + r] = lv;
+    }
+    bnr_wsync();
+    double g_tau = 1.0;
+    if (wave == 0) {
+        if (mask & (1 | 512)) {                                                   // theta (gibbs.jl:476-479) and the variate of the next tau2 (gibbs.jl:267-277)
+            const bool th = lane == 0 && (mask & 1), tn = lane == 1 && (mask & 512);
+            double g = 1.0;
+            if (th || tn) g = bnr_gamma(cd.seed, th ? cd.zeta + (V * (V + 1)) / 2.0 : (n / 2.0) + (V * (V + 1) / 4.0), th ? P.it : P.it + 1u, th ? SITE_THETA : SITE_TAU2, 0, &cap);
+            if (th) row[ROW_THETA] = g * (2.0 / (2.0 * cd.iota + sll[0]));
+            g_tau = bnr_readlane_c(g, 1);
         }
-    }
-    if (wave == 2 && lane == 0 && (mask & 8)) {                                  // mu (gibbs.jl:565-570)
-        double m = sres / n + sqrt(tau2 / n) * bnr_normal(cd.seed, P.it, SITE_MU, 0, 0);
-        row[ROW_MU] = m; sval[1] = m;
-    }
-    if (wave == 3 && (mask & (16 | 32))) {                                       // Lambda then pi (gibbs.jl:586-636)
-        if ((mask & 16) && lane < R) {
-            int r = lane;
-            double l0 = sll[1 + 3 * r], l1 = sll[2 + 3 * r], l2 = sll[3 + 3 * r];
-            double pmax = fmax(l0, fmax(l1, l2));
-            double w0 = prev[cd.o_pi + r] * exp(l0 - pmax), w1 = prev[cd.o_pi + r + R] * exp(l1 - pmax), w2 = prev[cd.o_pi + r + 2 * R] * exp(l2 - pmax);
-            double ua, ub;
-            bnr_draw2(cd.seed, P.it, SITE_LAMBDA, (uint32_t)r, 0, ua, ub);
-            double lv = bnr_lambda_value(bnr_categorical3(w0, w1, w2, ua));
-            row[cd.o_lam + r] = lv; slam[r] = lv;
-        }
-        bnr_wsync();
-        if (mask & 32) {
+        if (mask & 32) {                                                          // pi (gibbs.jl:620-636)
             for (int t0 = 0; t0 < 3 * R; t0 += 64) {
                 int t = t0 + lane;
                 if (t < 3 * R) {
@@ -2339,97 +2484,37 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
                     spi[t] = bnr_gamma(cd.seed, alpha, P.it, SITE_PI, (uint32_t)(3 * r + c), &cap);
                 }
             }
-        }
-    }
-    if (wave == 4 && (mask & 4)) {                                               // Bartlett diagonal: chi-square draws
-        for (int j = lane; j < R; j += 64) sBm[j + R * j] = sqrt(2.0 * bnr_gamma(cd.seed, 0.5 * (df - j), P.it, SITE_M_CHI, (uint32_t)j, &cap));
-    }
-    if (wave == 5 && (mask & 4)) {                                               // Bartlett strictly lower: normals; upper: 0
-#pragma unroll 1
-        for (int idx = lane; idx < R * R; idx += 64) {
-            int i = idx % R, j = idx / R;
-            if (i > j) sBm[idx] = bnr_normal(cd.seed, P.it, SITE_M_N, (uint32_t)(i * R + j), 0);
-            else if (i < j) sBm[idx] = 0.0;
-        }
-    }
-    if (wave == 6 && (mask & 4)) {                                               // C = chol(Psi), retry ladder gibbs.jl:529-543
-        int f = wave_chol(sA, R, lane);
-        if (f) {
-            if (lane == 0) atomicAdd((unsigned long long *)&cd.counters[0], 1ull);
-            for (int idx = lane; idx < R * R; idx += 64) sA[idx] = sPsi[idx] + ((idx % R == idx / R) ? 1e-5 : 0.0);
-            f = wave_chol(sA, R, lane);
-            if (f && lane == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[5], 1ull); }
-        }
-        for (int idx = lane; idx < R * R; idx += 64) { int a = idx % R, b = idx / R; if (a < b) sA[idx] = 0.0; }
-    }
-    __syncthreads();
-    BNR_TSTAMP(3);
-    if ((mask & 32) && tid < 3 * R) {
-        int r = tid / 3, c = tid % 3;
-        row[cd.o_pi + r + R * c] = spi[tid] / (spi[3 * r] + spi[3 * r + 1] + spi[3 * r + 2]);
-    }
-    // ---- phase 4 (wavefront 0 only, wave-level sync): M ~ InverseWishart(df, Psi) = (C A^-T)(C A^-T)', then inv(M), logdet M
-    if (wave == 0 && (mask & (4 | 256))) {
-        if (mask & 4) {
-            wave_tri_inverse(sBm, sT, R, lane);                                   // T = A^-1
-            for (int idx = lane; idx < R * R; idx += 64) {                        // B = C T' -> sPsi
-                int a = idx % R, b = idx / R;
-                double sacc = 0.0;
-                for (int k = 0; k < R; ++k) sacc += sA[a + R * k] * sT[b + R * k];
-                sPsi[idx] = sacc;
-            }
             bnr_wsync();
-            for (int idx = lane; idx < R * R; idx += 64) {                        // M = B B'
-                int a = idx % R, b = idx / R;
-                double sacc = 0.0;
-                for (int k = 0; k < R; ++k) sacc += sPsi[a + R * k] * sPsi[b + R * k];
-                row[cd.o_M + idx] = sacc;
-                sBm[idx] = sacc;
+            for (int t0 = 0; t0 < 3 * R; t0 += 64) {
+                int t = t0 + lane;
+                if (t < 3 * R) { int r = t / 3, c = t % 3; row[cd.o_pi + r + R * c] = spi[t] / (spi[3 * r] + spi[3 * r + 1] + spi[3 * r + 2]); }
             }
-        } else {
-            for (int idx = lane; idx < R * R; idx += 64) sBm[idx] = row[cd.o_M + idx];
-        }
-        bnr_wsync();
-        if (mask & 256) {
-            // inv(M) = Lm^-T Lm^-1 with Lm = chol(M) (gibbs.jl:315 computes inv(M); same matrix, triangular-inverse route)
-            for (int idx = lane; idx < R * R; idx += 64) sA[idx] = sBm[idx];
-            int f = wave_chol(sA, R, lane);
-            if (f && lane == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[6], 1ull); }
-            double ldm = 0.0;
-            for (int i = 0; i < R; ++i) ldm += 2.0 * log(sA[i + R * i]);
-            wave_tri_inverse(sA, sT, R, lane);                                    // Linv (lower)
-            for (int idx = lane; idx < R * R; idx += 64) {
-                int a = idx % R, b = idx / R, k0 = a > b ? a : b;
-                double sacc = 0.0;
-                for (int k = k0; k < R; ++k) sacc += sT[k + R * a] * sT[k + R * b];
-                cd.Minv[idx] = sacc;
-            }
-            if (lane == 0) cd.Minv[R * R] = ldm;
         }
     }
+    BNR_TSTAMP(3);
     BNR_TSTAMP(4);
-    // ---- phase 6: carried sums for the next update_tau2! (gibbs.jl:270-273): rr = |y - mu - X gamma|^2,
-    //      sig_q = sum_e ((gamma_e - W(u,lam)_e)^2 / 2) / S_e  with the NEW lambda; optionally pre-draw the next tau2
+    // ---- carried sums for the next update_tau2! (gibbs.jl:270-273): rr = |y - mu - X gamma|^2,
+    //      sig_q = sum_e ((gamma_e - W(u,lam)_e)^2 / 2) / S_e  with the NEW lambda; optionally the next tau2
     if (mask & 64) {
-        const double mu = sval[1];
         double racc = 0.0, qacc = 0.0;
-        if (wave != 0) {                          // wavefront 0 is busy with the matrix work above
+        if (wave != 0) {                          // (wavefront 0 stays out: the partition of the edges over 448 threads fixes the sums' last bits)
             const int t = tid - 64, nt = blockDim.x - 64;
             for (int i = t; i < n; i += nt) { double rv = cd.y[i] - mu - cd.xg[i]; racc += rv * rv; }
-            // four edges of a thread in flight per trip (their index / gamma / S loads are independent; one edge per trip was one round trip to memory per edge:
-            // 100 trips at q = 45 150 made this pass 100 of k_tail's 152 us there), the terms added in the same order as before
+            // four edges of a thread in flight per trip (their index / gamma / S loads are independent; one edge per trip is one round trip to memory per edge:
+            // 100 trips at q = 45 150 made this pass 100 of k_tail's 152 us there, and 11 trips at q = 5 050 were a third of the kernel once nothing hid them),
+            // the terms added in the same order as one by one
 #define BNR_TAIL_QPASS(SU)                                                                                                     \
             {                                                                                                                  \
                 int e = t;                                                                                                     \
-                if (q >= 16 * nt)            /* (short passes keep the plain loop: at q = 5 050, 11 edges per thread, the blocked form was 0.7 us per sweep slower) */ \
                 for (; e + 3 * nt < q; e += 4 * nt) {                                                                          \
                     int l4[4], k4[4]; double g4[4], s4[4];                                                                     \
                     _Pragma("unroll") for (int j = 0; j < 4; ++j) { const int ej = e + j * nt; l4[j] = cd.el[ej]; k4[j] = cd.ek[ej]; g4[j] = row[cd.o_gamma + ej]; s4[j] = row[cd.o_S + ej]; } \
                     _Pragma("unroll") for (int j = 0; j < 4; ++j) { const double g = g4[j] - edge_W(SU, slam, R, l4[j], k4[j]); qacc += ((g * g) / 2.0) / s4[j]; } \
                 }                                                                                                              \
-                for (; e < q; e += nt) {                                                                                       \
-                    double g = row[cd.o_gamma + e] - edge_W(SU, slam, R, cd.el[e], cd.ek[e]);                                  \
-                    qacc += ((g * g) / 2.0) / row[cd.o_S + e];                                                                 \
+                {                                    /* the last, ragged trip: up to three edges, in flight together as well */  \
+                    int l4[3], k4[3]; double g4[3], s4[3];                                                                     \
+                    _Pragma("unroll") for (int j = 0; j < 3; ++j) { const int ej = e + j * nt, ec = ej < q ? ej : 0; l4[j] = cd.el[ec]; k4[j] = cd.ek[ec]; g4[j] = row[cd.o_gamma + ec]; s4[j] = row[cd.o_S + ec]; } \
+                    _Pragma("unroll") for (int j = 0; j < 3; ++j) if (e + j * nt < q) { const double g = g4[j] - edge_W(SU, slam, R, l4[j], k4[j]); qacc += ((g * g) / 2.0) / s4[j]; } \
                 }                                                                                                              \
             }
             if (u_lds) BNR_TAIL_QPASS(su_lds)
@@ -2446,8 +2531,7 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
             cd.scal[SC_RR] = racc; cd.scal[SC_SIGQ] = qacc;
             if (mask & 512) {
                 double sigma = racc / 2.0 + qacc;
-                double shape = (n / 2.0) + (V * (V + 1) / 4.0);
-                cd.scal[SC_TAU2N] = sigma / bnr_gamma(cd.seed, shape, P.it + 1u, SITE_TAU2, 0, &cap);
+                cd.scal[SC_TAU2N] = sigma / g_tau;
                 cd.scal[SC_TAU2N_IT] = (double)(P.it + 1u);
             } else cd.scal[SC_TAU2N_IT] = -1.0;
         }
@@ -2787,14 +2871,19 @@ __device__ __forceinline__ void bnr_xg_dispatch(int nc, const XT *xp, size_t ld,
     }
 }
 template <int LATE>     // (a template only so that the kernel is emitted behind the others, with the instantiations: see the note above)
-__global__ __launch_bounds__(256) void k_xpass_group2(const bnr_many chain_src, int s, int nchains)
+__global__ __launch_bounds__(256) void k_xpass_group2(const bnr_many chain_src, int s, int nchains, int tail_mask)
 {
     if (BNR_EXP_SKIP_SCALAR()) return;
+    extern __shared__ double sh[];
+    int wg = blockIdx.x;
+    if (tail_mask) {                                       // the first nchains workgroups: Delta and M of this sweep beside the pass (bnr_tail_a)
+        if (wg < nchains) { const bnr_dev &ct = chain_src.at(wg); bnr_tail_a(ct, ct.plan[ct.pbase[0] + s], tail_mask, sh, threadIdx.x); return; }
+        wg -= nchains;
+    }
     const bnr_dev &c0 = chain_src.at(0);                  // the geometry and the shared X, index maps
-    const int rs = (c0.n_pad + 255) / 256, bid = blockIdx.x / rs, slice = blockIdx.x % rs, tid = threadIdx.x;
+    const int rs = (c0.n_pad + 255) / 256, bid = wg / rs, slice = wg % rs, tid = threadIdx.x;
     const int chunk = c0.chunk_x, e0 = bid * chunk, ne = min(chunk, c0.q - e0), R = c0.R;
     const size_t ld = c0.n_pad;
-    extern __shared__ double sh[];
     double *sWZ = sh;                                      // [column of the chunk][member][W, sqrt(S) z1]
     __shared__ double *s_pw[8], *s_pa[8];
     const int i = slice * 256 + tid;

@@ -284,6 +284,11 @@ double bnr_host_normal(uint64_t seed, uint32_t it, uint32_t site, uint32_t elem,
 double bnr_host_gamma(uint64_t seed, double shape, uint32_t it, uint32_t site, uint32_t elem);
 double bnr_host_gig(uint64_t seed, double lambda, double chi, double psi, uint32_t it, uint32_t elem);
 int32_t bnr_host_edge_index(int32_t V, int32_t l, int32_t k);   /* 0-based (l,k) -> 0-based e; utils.jl:50-55 */
+/* The K split the library would choose for the Gram  X diag(S) X'  of gibbs.jl:434 on a device with `ncu` compute units (no GPU needed):
+ * out[0] = K slices, out[1] = columns per slice (padded), out[2] = q_pad, out[3] = MiB of X one K-group of a workgroup addresses through its
+ * 2 GiB buffer window.  The split is raised beyond what fills the chip until that span fits the window (n up to the 14 000-row limit with any V
+ * the device holds); BNR_ERR_BAD_ARG when no split of at most 4096 slices does. */
+int bnr_host_gram_plan(int32_t n, int32_t V, int32_t ncu, int32_t out[4]);
 
 #ifdef __cplusplus
 }

@@ -417,3 +417,35 @@ def test_late_kernels_sit_behind_the_sweep_kernels_in_the_code_object(tmp_path):
     sweep = {k: v for k, v in addr.items() if k not in late and k.startswith(("k_chol_step", "k_gram", "k_solve", "k_rhs", "k_xpass", "k_backproj", "k_node", "k_tail", "k_sdigits"))}
     assert len(late) >= 5 and len(sweep) >= 20, (sorted(late), len(sweep))
     assert min(late.values()) > max(sweep.values()), (sorted(late.items(), key=lambda kv: kv[1])[:2], sorted(sweep.items(), key=lambda kv: -kv[1])[:2])
+
+
+def test_gram_k_split_keeps_every_k_group_inside_the_buffer_window():
+    """the Gram loops address X through a 2 GiB buffer resource with 32-bit scalar offsets (csrc/bnr_kernels.h, bnr_gram16_task /
+    bnr_gram8_task; reference product gibbs.jl:434).  The K split must be raised until one K-group's slice + prefetch distance fits that window --
+    n = 14 000 with V >= 280 and n = 8 000 with V >= 520 used to overflow silently.  Pure host arithmetic: no GPU."""
+    import ctypes as C
+    L = bnr_amd.lib()
+    out = (C.c_int32 * 4)()
+    # the shapes every earlier round ran: the split that fills the chip is kept as it was
+    for (n, V, want) in [(500, 100, 7), (200, 50, None), (2000, 200, None), (500, 300, None)]:
+        assert L.bnr_host_gram_plan(n, V, 256, out) == 0
+        ks, kchunk, q_pad, mib = out[0], out[1], out[2], out[3]
+        q = V * (V + 1) // 2
+        assert q_pad == ks * kchunk >= q and kchunk % 16 == 0
+        if want is not None:
+            assert ks == want
+        assert mib < 2048
+    # at and beyond the old silent-overflow boundary
+    for (n, V) in [(14000, 280), (14000, 400), (8000, 520), (8000, 700), (14000, 1000)]:
+        assert L.bnr_host_gram_plan(n, V, 256, out) == 0
+        ks, kchunk, q_pad = out[0], out[1], out[2]
+        n_pad = (n + 63) // 64 * 64
+        span = (kchunk // 2 + 64 + 16) * n_pad * 8         # bnr_gram_span_bytes: the K-group's columns, the prefetch distance, the widest lane offset
+        assert span <= 0x7FFFFFFF, (n, V, ks, span)
+        assert q_pad >= V * (V + 1) // 2
+        # and not split further than needed: one slice fewer would not fit (or the chip-filling split was already fine)
+        if ks > 32:
+            k1 = -(-(V * (V + 1) // 2) // (ks - 1))
+            k1 = (k1 + 15) // 16 * 16
+            assert (k1 // 2 + 80) * n_pad * 8 > 0x7FFFFFFF
+    assert L.bnr_host_gram_plan(0, 5, 256, out) != 0
