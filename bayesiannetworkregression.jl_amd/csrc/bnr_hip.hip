@@ -69,6 +69,10 @@ struct bnr_exec {
     int wide_backproj = -1;                              // 1: k_backproj64 (64 edges per workgroup, one edge per lane of the drawing wave); -1: launches of many rounds (a group at large q)
     int split_sums = -1;                                 // 1: the back-projection's partial sums as a launch of their own in front of the scalar tail (off the critical chain)
     int spw_cap = 4;                                    // super blocks per update workgroup of the factorization, at most
+    // Round 6: WHEN the scalar branch's kernels start is part of the schedule (profiles/round6_experiments_notes.txt A): inside the two-branch sweep they are ordered behind
+    // points of the critical chain by events (graph edges), instead of starting whenever the dispatcher lets the second queue in.
+    int tail_after = -2;                                // k_tail(s-1) waits for: -1 nothing (rounds 1-5), 0 the Gram of sweep s; -2: default by size (tail_after_default)
+    int node_after = -2;                                // k_node(s) waits for factorization launch number node_after (0-based; -1 nothing); -2: default by size (node_after_default)
     int factor_variant = -1;                            // -1: chosen by size; 0: right-looking k_chol_step (+ k_gram_reduce); 1: left-looking k_chol_ll
     int use_graph = 1, graph_k = 16;                     // (round 5: 16, was 8 -- between two graph launches the GPU idles ~30 us: 640 sweeps 382.2 -> 380.1 us each, 20 sweeps = 16 + 4 instead of 8 + 8 + 4)
     struct rung { int k; hipGraph_t graph; hipGraphExec_t gexec; };
@@ -833,9 +837,12 @@ static int build_qlist(bnr_exec &) { return BNR_OK; }
 static bool wants_qlist(const bnr_exec &x);
 static bool wants_qlist(const bnr_exec &) { return false; }
 static void launch_rhs(bnr_exec &x, int s) { BNR_LAUNCH(k_rhs, dim3(x.shape->n_pad / 64, 1, x.nb), dim3(256), 0, x.stream, x, s); }
-static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
+static void launch_chol(bnr_exec &x, int s, hipStream_t st, int rec_p = -1, hipEvent_t rec_ev = nullptr)
 {
     const int nbk = x.shape->n_pad / BNR_NB;
+    int nlaunch = 0;
+    // (after launch number rec_p of the factorization the event rec_ev is recorded: the scalar branch's k_node waits for it)
+#define BNR_CHOL_LAUNCHED() do { if (rec_ev && nlaunch == rec_p) HIPNOTE(hipEventRecord(rec_ev, st)); ++nlaunch; } while (0)
     if (x.factor_variant == 2 || x.factor_variant == 3 || (x.factor_variant < 0 && two_panel_default(x))) {
         // two panels per launch (k_chol_step2): half the launches on the critical path, the same arithmetic; variant 3 (the choice for
         // large n): the whole trailing matrix is read and written at every other launch only, with K = 128
@@ -844,10 +851,10 @@ static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
             const int nsup = bnr_chol2_nsuper(nbk, P, lazy), freecu = ncu - x.nb * nbk;
             const int spw = (freecu > 0 && nbk <= 24 && nsup > 0) ? std::min(x.spw_cap, std::max(1, (x.nb * nsup + freecu - 1) / freecu)) : 1;
             BNR_LAUNCH(k_chol_step2, dim3(x.nb, nbk + (nsup + spw - 1) / spw), dim3(256), 0, st, x, P, s, spw, lazy);
+            BNR_CHOL_LAUNCHED();
         }
         return;
     }
-    (void)spin_us;
     // update workgroups: one 32 x 32 block each while panels + updates of all members fit the chip in one round (two 256-thread
     // workgroups per CU); otherwise (large n, groups) 64 x 64 super blocks
     const int ncu = x.ncu, fuse0 = reduce_in_chol(x) ? 1 : 0;
@@ -865,6 +872,7 @@ static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
             // launch 0: the first panel (its workgroups sum the partial tiles of column block 0 themselves) beside the reduction of all the other tiles
             const int ntl = x.shape->ntile * (x.shape->ntile + 1) / 2;
             BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + 8 * ntl), dim3(256), 0, st, x, p, s, 1, 1, 1);
+            BNR_CHOL_LAUNCHED();
             continue;
         }
         const int room = std::max(64, 2 * ncu - x.nb * npan);
@@ -887,8 +895,41 @@ static void launch_chol(bnr_exec &x, int s, hipStream_t st, int spin_us = 0)
             if (few_ok && p >= 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_step<bnr_few>), dim3(x.nb, npan + ntile), dim3(256), 0, st, few, p, s, 1, 1, fuse0);
             else BNR_LAUNCH(k_chol_step, dim3(x.nb, npan + ntile), dim3(256), 0, st, x, p, s, 1, 1, fuse0);
         }
+        BNR_CHOL_LAUNCHED();
     }
+#undef BNR_CHOL_LAUNCHED
 }
+// Number of launches of the factorization, and where the scalar branch is ordered behind the critical chain by default.
+static int chol_launches(const bnr_exec &x)
+{
+    const int nbk = x.shape->n_pad / BNR_NB;
+    return (x.factor_variant == 2 || x.factor_variant == 3 || (x.factor_variant < 0 && two_panel_default(x))) ? nbk / 2 : nbk;
+}
+// Ordering the scalar branch behind points of the critical chain pays where the factorization is the longer of the two chains behind the Gram by a margin (each
+// edge costs the waiting queue ~9 us in a replayed graph): measured per sweep, edges on / off (profiles/round6_experiments_notes.txt A) -- headline shape one chain
+// 175.1 / 180.1 us, 8 chains 371.0 / 378.0; n = 2000, V = 200: 2 075 / 2 134; but n = 200, V = 50: 100.4 / 94.6, n = 70: 90.4 / 83.9, n = 500, V = 300 (the
+// scalar branch is the longer chain): 471 / 394.  Rough per-launch and per-kernel times of this chip stand in for a measurement at creation time.
+static double fact_est_us(const bnr_exec &x)
+{
+    const bool two_panel = chol_launches(x) != x.shape->n_pad / BNR_NB;
+    return chol_launches(x) * (two_panel ? 18.5 : (x.nb > 1 ? 8.0 : 7.0));
+}
+static double scalar_est_us(const bnr_exec &x)           // k_tail + k_node + X pass + k_rhs
+{
+    return 45.0 + 0.0025 * x.shape->q * (x.nb > 1 ? 1.5 : 1.0) + 0.15 * x.shape->V * (x.nb > 1 ? 1.3 : 1.0);
+}
+static bool order_scalar_branch(const bnr_exec &x) { return x.overlap != 0 && fact_est_us(x) - scalar_est_us(x) >= 25.0; }
+static int tail_after_default(const bnr_exec &x) { return order_scalar_branch(x) ? 0 : -1; }
+static int node_after_default(const bnr_exec &x)
+{
+    if (!order_scalar_branch(x)) return -1;
+    // k_node starts when what is left of the factorization is about k_node + X pass + k_rhs long (+ 20 us), at most a quarter into it
+    const double per = fact_est_us(x) / chol_launches(x);
+    const int p = (int)((fact_est_us(x) - (scalar_est_us(x) - 20.0) - 20.0) / per);
+    return std::max(0, std::min(p, chol_launches(x) / 4));
+}
+static int tail_after(const bnr_exec &x) { return x.tail_after == -2 ? tail_after_default(x) : x.tail_after; }
+static int node_after(const bnr_exec &x) { const int v = x.node_after == -2 ? node_after_default(x) : x.node_after; return std::min(v, chol_launches(x) - 1); }
 static void launch_solve(bnr_exec &x)
 {
     BNR_LAUNCH(k_solve_w, dim3(x.shape->n_pad / 4, 1, x.nb), dim3(256), 0, x.stream, x);
@@ -912,6 +953,9 @@ static void launch_backproj(bnr_exec &x, int s, int flags)
 }
 static void launch_tail(bnr_exec &x, int s, int mask, int xg_src)
 {
+#ifdef BNR_EXP_PAD
+    { static const int pad = getenv("BNR_EXP_TAIL_PAD_US") ? atoi(getenv("BNR_EXP_TAIL_PAD_US")) : 0; if (mask == (1023 & ~BNR_TAIL_EARLY)) xg_src |= pad << 8; }
+#endif
     const size_t rv = (size_t)x.shape->R * x.shape->V;
     const size_t lds_a = (mask & BNR_TAIL_EARLY) ? tail_a_bytes(x) : 0;       // Delta / M / inv(M) asked for here (hooks, a loaded row): bnr_tail_a's work matrices behind u
     if (rv <= BNR_TAIL_U_LDS) { BNR_LAUNCH(k_tail, dim3(1, 1, x.nb), dim3(BNR_TAIL_THREADS), rv * sizeof(double) + lds_a, x.stream, x, s, mask, xg_src); return; }
@@ -964,9 +1008,16 @@ static void launch_sweep(bnr_exec &x, int s, bool prev_tail)
         HIPNOTE(hipEventRecord(ef, x.stream));
         HIPNOTE(hipStreamWaitEvent(x.stream2, ef, 0));
         launch_gram(x, s, sb, timed);
-        launch_chol(x, s, sb);
+        hipEvent_t eg = nullptr, en = nullptr;
+        if (tail_after(x) == 0 && prev_tail) { HIPNOTE(hipEventRecord(eg = next_event(x), x.stream2)); }
+        if (node_after(x) >= 0) en = next_event(x);
+        launch_chol(x, s, sb, node_after(x), en);
         HIPNOTE(hipEventRecord(ej[0] = next_event(x), x.stream2));
-    }
+        // the scalar branch is ordered behind points of the critical chain (see bnr_exec::tail_after / node_after)
+        if (eg) HIPNOTE(hipStreamWaitEvent(x.stream, eg, 0));
+        if (prev_tail) launch_full_tail(x, s - 1);
+        if (en) HIPNOTE(hipStreamWaitEvent(x.stream, en, 0));
+    } else
     if (prev_tail) launch_full_tail(x, s - 1);
     launch_node(x, s, 3);
     launch_xpass(x, s, 3, BNR_TAIL_EARLY);
@@ -1351,6 +1402,14 @@ static int exec_set_option(bnr_exec &x, const char *name, int64_t value)
     if (!strcmp(name, "wide_backproj")) {
         if (value < -1 || value > 1) return fail(BNR_ERR_BAD_ARG, "wide_backproj must be -1 (default: launches of many rounds), 0 or 1");
         x.wide_backproj = (int)value; drop_graph(x); return BNR_OK;
+    }
+    if (!strcmp(name, "tail_after")) {
+        if (value < -2 || value > 0) return fail(BNR_ERR_BAD_ARG, "tail_after must be -2 (default), -1 (no ordering) or 0 (behind the Gram)");
+        x.tail_after = (int)value; drop_graph(x); return BNR_OK;
+    }
+    if (!strcmp(name, "node_after")) {
+        if (value < -2 || value > 1024) return fail(BNR_ERR_BAD_ARG, "node_after must be -2 (default), -1 (no ordering) or a launch number of the factorization");
+        x.node_after = (int)value; drop_graph(x); return BNR_OK;
     }
     if (!strcmp(name, "spw_cap")) {
         if (value < 1 || value > 4) return fail(BNR_ERR_BAD_ARG, "spw_cap must be 1..4");
