@@ -68,7 +68,7 @@ struct bnr_exec {
     std::vector<lrung> lladder;
     int wide_backproj = -1;                              // 1: k_backproj64 (64 edges per workgroup, one edge per lane of the drawing wave); -1: launches of many rounds (a group at large q)
     int split_sums = -1;                                 // 1: the back-projection's partial sums as a launch of their own in front of the scalar tail (off the critical chain)
-    int spw_cap = 4;                                    // super blocks per update workgroup of the factorization, at most
+    int spw_cap = 1;                                    // super blocks per update workgroup of the factorization, at most (round 6: 1 -- with the pipelined panel sweep one block each is the shorter launch: 8 chains 369.4 against 372-374 us per sweep; rounds 3-5 packed up to 4 behind the single sweeping wave)
     // Round 6: WHEN the scalar branch's kernels start is part of the schedule (profiles/round6_experiments_notes.txt A): inside the two-branch sweep they are ordered behind
     // points of the critical chain by events (graph edges), instead of starting whenever the dispatcher lets the second queue in.
     int tail_after = -2;                                // k_tail(s-1) waits for: -1 nothing (rounds 1-5), 0 the Gram of sweep s; -2: default by size (tail_after_default)

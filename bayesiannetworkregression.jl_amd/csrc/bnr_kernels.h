@@ -1335,6 +1335,9 @@ __device__ __forceinline__ double bnr_readlane(double v, int srclane)
     return __hiloint2double(hi, lo);
 }
 #define BNR_LP (BNR_NB + 1)
+#ifndef BNR_PANEL_PIPE
+#define BNR_PANEL_PIPE 1      // 1: the panel sweep as a pipeline of the workgroup's four waves (round 6, bnr_panel_sweep_pipe); 0: one sweeping wave (rounds 1-5)
+#endif
 __host__ __device__ inline int bnr_chol_npanel(int nbk, int p) { (void)p; return nbk + 1; }
 __host__ __device__ inline int bnr_chol_ntile(int nbk, int p)
 {
@@ -1514,6 +1517,210 @@ __device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &
     }
     return bad;
 }
+// ----------------------------------------------------------------------------------------- round 6: the panel sweep as a pipeline of the four waves
+// bnr_panel_sweep above leaves three of the workgroup's four SIMDs idle while ONE wave walks the 32 pivots with all the rank-1 updates of the columns to their
+// right (45 instructions per pivot at one issue per 4 cycles: 2 x 3 000 cycles, + 1 200 for the MFMA update between the two 16-column halves).  Here every wave owns
+// EIGHT of the 32 columns (lane = row as before: lanes 0..31 the diagonal block, 32..63 the own block) and the waves form a pipeline over the columns:
+//   wave w first applies the finished columns 0 .. 8w-1 to its own eight as they show up in LDS (sL: one 64-row column per pivot, published by the wave that owns
+//   it the moment it is scaled), two columns per trip, ten LDS reads in flight; then it walks its own eight pivots (bnr_sweepN<8>: the pivot chain on wave-uniform
+//   scalars as before, the rank-1 updates now reach at most seven columns to the right) and publishes each column.
+// The pivot chain runs through the four waves in turn; what a wave's predecessors publish while they are the chain is applied by the waves behind, off the chain.
+// Nothing is ordered by barriers: a column that is not there yet shows as a NaN with a payload no arithmetic produces (sL is filled with it before the panel is
+// staged), every lane checks its own row and a wave vote says "all 64 rows there" -- which is the whole column, multipliers included.  The polls are bounded: a
+// column that never shows up (it cannot, short of a fault) ends the wait after BNR_PIPE_SPINS polls and reports the panel as failed.
+// Per element the updates arrive in column order except for the swap inside bnr_sweepN (k-2 before k-3): deterministic, independent of timing; NOT the summation
+// order of bnr_panel_sweep's MFMA mid update, so the factor differs from the round-5 build's in the last bits (rtol 1e-6 against the oracle is the bar).
+#define BNR_PIPE_SPINS (1 << 16)
+#ifndef BNR_PIPE_TIE
+#define BNR_PIPE_TIE 0      // 1: the publishing store tied to the block's last column instead of the next pivot (measured slower: one chain 172-174 against 168 us per sweep)
+#endif
+#ifndef BNR_PIPE_HEAVY
+#define BNR_PIPE_HEAVY 0    // 1: a starved wave polls with all ten reads instead of one (one chain 169.5 against 168.0 us per sweep)
+#endif
+#define BNR_PIPE_SENT_HI 0x7FF8DEAD
+struct bnr_panelp_lds {
+    double sD[BNR_NB * BNR_LP], sB[BNR_NB * BNR_LP];
+    double sL[BNR_NB][64];
+#ifdef BNR_STAMPS
+    unsigned long long st[4][24];          // per wave: [0..11] when a trip's pair of columns was there, [12..19] when an own column was published, [20] polls
+#endif
+};
+__device__ __forceinline__ unsigned bnr_lds_addr(const void *p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void *)p; }
+// sweep of N panel columns held one row per lane: column j's pivot sits in lane COFF + j.  PUB: 0 nothing, 2 every finished column goes to pub + 512 j bytes (LDS, lane = row)
+template <int N, int COFF, int PUB>
+__device__ __forceinline__ int bnr_sweepN(double (&a)[N], int lane, unsigned pub_addr, unsigned long long *pst = nullptr)
+{
+    int bad = 0;
+    double lprev = 0.0;
+    double piv = bnr_readlane(a[0], COFF);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double tk[N];
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (j + 1 < N) { s1 = bnr_readlane(a[j + 1], COFF + j + 1); s2 = bnr_readlane(a[j], COFF + j + 1); }
+        if (j + 2 < N) s3 = bnr_readlane(a[j], COFF + j + 2);
+        if (!(piv > 0.0)) bad = 1;
+        double y = __builtin_amdgcn_rsq(piv);
+        if (j >= 1) {
+#pragma unroll
+            for (int k = j + 2; k < N; ++k) tk[k] = bnr_readlane(lprev, COFF + k);
+        }
+        const double e = fma(-(piv * y), y, 1.0);
+        const double rinv = fma(y * e, fma(0.375, e, 0.5), y);
+        const double t1 = s2 * rinv;
+        piv = fma(-t1, t1, s1);
+        double lj = a[j] * rinv;
+        a[j] = lj;
+        // (the store names a register of the sweep as an in/out operand: without such a tie the scheduler walks the whole pivot chain first and sinks all N stores behind
+        // it -- the waves behind would see the columns only when this wave is done.  The last column of the block is the register: every pivot's lagged update touches it,
+        // so the stores stay one per pivot and in order, but off the rsq chain; the next pivot itself for the last columns, which have no such update left)
+        if (PUB == 2) {
+            if (BNR_PIPE_TIE && j + 3 < N) asm volatile("ds_write_b64 %1, %2 offset:%3" : "+v"(a[N - 1]) : "v"(pub_addr), "v"(lj), "n"(512 * j) : "memory");
+            else asm volatile("ds_write_b64 %1, %2 offset:%3" : "+v"(piv) : "v"(pub_addr), "v"(lj), "n"(512 * j) : "memory");
+        }
+#ifdef BNR_STAMPS
+        if (pst && lane == 0) pst[j] = __builtin_amdgcn_s_memtime();
+#endif
+        if (j + 1 < N) a[j + 1] = fma(-lj, t1, a[j + 1]);
+        if (j + 2 < N) a[j + 2] = fma(-lj, s3 * rinv, a[j + 2]);
+        if (j >= 1) {
+#pragma unroll
+            for (int k = j + 2; k < N; ++k) a[k] = fma(-lprev, tk[k], a[k]);
+        }
+        lprev = lj;
+    }
+    return bad;
+}
+template <int W>
+__device__ __forceinline__ int bnr_pipe_wave(bnr_panelp_lds &sh, int lane, double *dst, size_t ld, unsigned long long *ph = nullptr)
+{
+#ifdef BNR_STAMPS
+#define BNR_PPH(i) do { if (ph && lane == 0) ph[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BNR_PPH(i) do { } while (0)
+#endif
+    constexpr int C0 = 8 * W;
+    const int rr = lane & 31;
+    const double *src = (lane < 32) ? sh.sD : sh.sB;
+    double a[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a[c] = src[rr + BNR_LP * (C0 + c)];
+    int bad = 0;
+    // the columns of the waves in front, two per trip: this lane's row of both columns (ds_read_b64) and their eight multipliers each -- rows C0 .. C0 + 7 of the
+    // column, the same address in every lane: four ds_read_b128 -- ; the ten reads of the NEXT trip are in flight under this trip's sixteen multiply-adds.  A wave that
+    // has caught up with the publishing wave polls with ONE read (its row of the later column) and fetches the other nine when that shows up.
+    // (multipliers by v_readlane out of the column's register instead: 16 + 16 v_readlane_b32 per column pair made a trip 420-500 cycles -- the waves behind fell a whole
+    // block of columns behind the chain and every hand-over waited 1 300 cycles for them, profiles/round6_experiments_notes.txt B)
+    unsigned vcol = bnr_lds_addr(&sh.sL[0][lane]), vmul = bnr_lds_addr(&sh.sL[0][C0]);
+    double c0 = 0.0, c1 = 0.0, n0 = 0.0, n1 = 0.0;
+    bnr_d2 m[8], mn[8];
+    // (OFF: byte offset of the column pair relative to the running addresses vcol / vmul)
+#define BNR_PIPE_READ10(X0, X1, M, OFF)                                                                                                                      \
+    asm volatile("ds_read_b64 %0, %10 offset:%12\n\tds_read_b64 %1, %10 offset:%13\n\t"                                                                      \
+                 "ds_read_b128 %2, %11 offset:%12\n\tds_read_b128 %3, %11 offset:%14\n\tds_read_b128 %4, %11 offset:%15\n\tds_read_b128 %5, %11 offset:%16\n\t" \
+                 "ds_read_b128 %6, %11 offset:%13\n\tds_read_b128 %7, %11 offset:%17\n\tds_read_b128 %8, %11 offset:%18\n\tds_read_b128 %9, %11 offset:%19"      \
+                 : "=&v"(X0), "=&v"(X1), "=&v"(M[0]), "=&v"(M[1]), "=&v"(M[2]), "=&v"(M[3]), "=&v"(M[4]), "=&v"(M[5]), "=&v"(M[6]), "=&v"(M[7])              \
+                 : "v"(vcol), "v"(vmul), "n"(OFF), "n"((OFF) + 512), "n"((OFF) + 16), "n"((OFF) + 32), "n"((OFF) + 48),                                      \
+                   "n"((OFF) + 528), "n"((OFF) + 544), "n"((OFF) + 560) : "memory");                                                                         \
+    /* (and an empty statement that names the accumulators: the multiply-adds that follow in the source stay behind the reads) */                            \
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
+    // (the wait names the trip's accumulators as operands too: the multiply-adds of the trip before stay in front of it, under the reads in flight)
+#define BNR_PIPE_WAIT10(X0, X1, M) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X0), "+v"(X1), "+v"(M[0]), "+v"(M[1]), "+v"(M[2]), "+v"(M[3]), "+v"(M[4]), "+v"(M[5]), "+v"(M[6]), "+v"(M[7]), \
+                                                "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) :: "memory")
+#define BNR_PIPE_POLL1(X1, OFF) asm volatile("ds_read_b64 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(X1) : "v"(vcol), "n"((OFF) + 512) : "memory")
+#define BNR_PIPE_HERE(X0, X1) __all(__double2hiint(X0) != BNR_PIPE_SENT_HI && __double2hiint(X1) != BNR_PIPE_SENT_HI)
+    // one trip: the pair at OFF is in flight into (X0, X1, M); wait, poll if it is not there yet, start the next pair's reads into (Y0, Y1, MY), apply
+#define BNR_PIPE_TRIP(X0, X1, M, OFF, Y0, Y1, MY, MORE)                                                                  \
+    do {                                                                                                                \
+        BNR_PIPE_WAIT10(X0, X1, M);                                                                                     \
+        if (!BNR_PIPE_HERE(X0, X1)) {                                                                                   \
+            int spins = 0;                                                                                              \
+            if (BNR_PIPE_HEAVY) {                                                                                       \
+            do {                                     /* (every poll is the ten reads: one LDS round trip between a publication and its use, not two) */ \
+                ++npoll;                                                                                                \
+                if (++spins > BNR_PIPE_SPINS) { bad = 1; break; }                                                       \
+                BNR_PIPE_READ10(X0, X1, M, OFF);                                                                        \
+                BNR_PIPE_WAIT10(X0, X1, M);                                                                             \
+            } while (!BNR_PIPE_HERE(X0, X1));                                                                           \
+            } else {                                                                                                    \
+            do {                                                                                                        \
+                ++npoll;                                                                                                \
+                if (++spins > BNR_PIPE_SPINS) { bad = 1; break; }                                                       \
+                BNR_PIPE_POLL1(X1, OFF);                                                                                \
+            } while (!__all(__double2hiint(X1) != BNR_PIPE_SENT_HI));                                                   \
+            BNR_PIPE_READ10(X0, X1, M, OFF);                                                                            \
+            BNR_PIPE_WAIT10(X0, X1, M);                                                                                 \
+            }                                                                                                           \
+        }                                                                                                               \
+        BNR_PIPE_TSTAMP();                                                                                              \
+        if (MORE) BNR_PIPE_READ10(Y0, Y1, MY, (OFF) + 1024);                                                            \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) a[c] = fma(-(X0), M[c >> 1][c & 1], a[c]);                         \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) a[c] = fma(-(X1), M[4 + (c >> 1)][c & 1], a[c]);                   \
+    } while (0)
+    int ntrip = 0, npoll = 0;
+#ifdef BNR_STAMPS
+#define BNR_PIPE_TSTAMP() do { if (lane == 0) sh.st[W][ntrip] = __builtin_amdgcn_s_memtime(); ++ntrip; } while (0)
+#else
+#define BNR_PIPE_TSTAMP() do { } while (0)
+#endif
+    if (W > 0) {
+        BNR_PIPE_READ10(c0, c1, m, 0);
+#pragma unroll 1
+        for (int j = 0; j < C0; j += 4) {                   // two trips per turn: the two register sets take turns without copies (C0 is a multiple of 8)
+            BNR_PIPE_TRIP(c0, c1, m, 0, n0, n1, mn, true);
+            BNR_PIPE_TRIP(n0, n1, mn, 1024, c0, c1, m, j + 4 < C0);
+            vcol += 2048; vmul += 2048;
+        }
+    }
+    if (W == 1) BNR_PPH(3);
+    if (W == 3) BNR_PPH(6);
+#ifdef BNR_STAMPS
+    bad |= bnr_sweepN<8, C0, (W < 3 ? 2 : 0)>(a, lane, bnr_lds_addr(&sh.sL[C0][lane]), &sh.st[W][12]);
+#else
+    bad |= bnr_sweepN<8, C0, (W < 3 ? 2 : 0)>(a, lane, bnr_lds_addr(&sh.sL[C0][lane]));
+#endif
+#ifdef BNR_STAMPS
+    if (ph && lane == 0) { sh.st[W][20] = (unsigned long long)npoll; for (int i = 0; i < 24; ++i) ph[1024 + 24 * W + i] = sh.st[W][i]; }
+#endif
+    (void)ntrip; (void)npoll;
+    if (W == 0) BNR_PPH(2);
+    if (W == 1) BNR_PPH(4);
+    if (W == 2) BNR_PPH(5);
+    if (W == 3) BNR_PPH(7);
+    if (dst && lane >= 32) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dst[(size_t)rr + ld * (size_t)(C0 + c)] = a[c];
+    }
+    return bad;
+}
+// same contract as bnr_panel_sweep (D, B as the MFMA accumulator fragments of the four waves; the swept own block goes to dst); returns 1 in the waves that met
+// a non-positive pivot (any wave may)
+__device__ __forceinline__ int bnr_panel_sweep_pipe(bnr_panelp_lds &sh, const bnr_d4 &cD, const bnr_d4 &cB, int tid, double *dst, size_t ld, unsigned long long *ph = nullptr)
+{
+    const int wave = tid >> 6, lane = tid & 63, mt = wave >> 1, nt = wave & 1, ln = lane & 15, lq = lane >> 4;
+#ifdef BNR_STAMPS
+    if (ph && tid == 0) ph[0] = __builtin_amdgcn_s_memtime();
+#endif
+    {
+        const double sent = __hiloint2double(BNR_PIPE_SENT_HI, 0);
+        double *sl = &sh.sL[0][0];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sl[tid + 256 * i] = sent;      // columns 0..23: what the waves 0..2 will publish
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sh.sD[(nt * 16 + ln) + BNR_LP * (mt * 16 + lq + 4 * r)] = cD[r];
+        sh.sB[(nt * 16 + ln) + BNR_LP * (mt * 16 + lq + 4 * r)] = cB[r];
+    }
+    __syncthreads();
+#ifdef BNR_STAMPS
+    if (ph && tid == 0) ph[1] = __builtin_amdgcn_s_memtime();
+#endif
+    if (wave == 0) return bnr_pipe_wave<0>(sh, lane, dst, ld, ph);
+    if (wave == 1) return bnr_pipe_wave<1>(sh, lane, dst, ld, ph);
+    if (wave == 2) return bnr_pipe_wave<2>(sh, lane, dst, ld, ph);
+    return bnr_pipe_wave<3>(sh, lane, dst, ld, ph);
+}
 // First touch of G + I: the 32 x 32 block (rho, c), rho >= c, as MFMA accumulator fragments -- NT x NT tiles of 16 x 16 starting at
 // tile (at0, bt0) (columns at, rows bt; lane: row 16 bt + ln, columns 16 at + lq + 4 r) -- with the K-slice partials summed per
 // element in k_gram_reduce's order (ks ascending from 0.0, then + 1 on the diagonal).  The loop runs over the K slices with
@@ -1613,7 +1820,11 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
     BNR_CRITICAL_PATH();
     if (BNR_EXP_SKIP_CHOL(p)) return;
     const bnr_dev &cd = chain_src.get_x();               // grid = (chains, workgroups): blockIdx.x = chain, blockIdx.y = workgroup
+#if BNR_PANEL_PIPE
+    __shared__ bnr_panelp_lds sh;
+#else
     __shared__ bnr_panel_lds sh;
+#endif
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nbk = cd.n_pad / BNR_NB;
     const size_t ld = bnr_ldE(cd.n_pad);
     const int npanel = bnr_chol_npanel(nbk, p);
@@ -1768,16 +1979,25 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
     // (the factored diagonal block L_pp is needed by nobody after this launch and is NOT written back: every panel workgroup of
     // this launch reads the unfactored block (p,p) whenever it happens to start)
     double *dst = rho != p ? E + (size_t)(rho * BNR_NB) + ld * (size_t)pc : nullptr;
+#if BNR_PANEL_PIPE
+#ifdef BNR_STAMPS
+    const int bad = bnr_panel_sweep_pipe(sh, cD, cB, tid, dst, ld, b == 0 ? cd.dbg + 128 + p * 8 : nullptr);
+#else
+    const int bad = bnr_panel_sweep_pipe(sh, cD, cB, tid, dst, ld);
+#endif
+    if (bad && lane == 0 && b == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[7], 1ull); }
+#else
 #ifdef BNR_STAMPS
     const int bad = bnr_panel_sweep(sh, cD, cB, tid, dst, ld, b == 0 ? cd.dbg + 128 + p * 8 : nullptr);
 #else
     const int bad = bnr_panel_sweep(sh, cD, cB, tid, dst, ld);
 #endif
     if (bad && tid == 0 && b == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[7], 1ull); }
+#endif
     BNR_STAMP(3);
     BNR_STAMP(4);
 #ifdef BNR_STAMPS
-    if (tid == 0) atomicMax((unsigned long long *)&cd.dbg[p * 8 + 5], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (lane == 0) atomicMax((unsigned long long *)&cd.dbg[p * 8 + 5], (unsigned long long)__builtin_amdgcn_s_memrealtime());      // (every wave: with the pipelined sweep wave 3 is the last one)
 #endif
 }
 

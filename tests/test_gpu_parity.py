@@ -1375,11 +1375,21 @@ def test_factorization_variants_are_bitwise_equal(gpu):
             g.close()
             for c in [ch, solo] + mates:
                 c.close()
+        # Round 6: the one-panel kernel's sweep is a pipeline of the workgroup's four waves (bnr_panel_sweep_pipe: rank-1 updates column by column), the two-panel kernel
+        # keeps the single sweeping wave with an MFMA update between its halves -- two summation orders of the same factor.  Bitwise equality holds inside each family
+        # (every schedule / launch mode / group membership of a kernel); across the families the tables agree to rounding.
         for name, (grp, alone) in tabs.items():
+            ref = tabs["two panels"] if name.startswith("two panels") else tabs["right"]
             for k in bo.COLUMNS:
-                assert np.array_equal(grp[k], tabs["right"][0][k]), (name, "group", n, V, R, k)
-                assert np.array_equal(alone[k], tabs["right"][1][k]), (name, "alone", n, V, R, k)
+                assert np.array_equal(grp[k], ref[0][k]), (name, "group", n, V, R, k)
+                assert np.array_equal(alone[k], ref[1][k]), (name, "alone", n, V, R, k)
                 assert np.array_equal(grp[k], alone[k]), (name, "group vs alone", n, V, R, k)
+        for k in bo.COLUMNS:
+            a, b = tabs["two panels"][1][k], tabs["right"][1][k]
+            if k in ("xi", "lam"):
+                assert np.array_equal(a, b), ("families", n, V, R, k)
+            else:
+                assert np.allclose(a, b, rtol=1e-7, atol=1e-9), ("families", n, V, R, k, float(np.max(np.abs(a - b))))
 
 
 def test_back_projection_with_one_edge_per_lane_is_bitwise_equal(gpu):
