@@ -1361,8 +1361,12 @@ int bnr_group_run(bnr_group *g, int32_t first_index, int32_t nburn, int32_t tota
     if (rc) return rc;
     for (size_t i = 0; i < g->m.size(); ++i) {
         g->m[i]->carried_row = g->m[i]->plan_pin[count].row;
+        // the most severe member status wins: a sampler that stopped at its attempt cap (a warning to the callers: the table stays valid) must not hide a member whose
+        // factorization failed or whose launches ran out of order in the same call
+        std::string msg_before = g_err;
         int r2 = status_of(g->x.status_pin + 16 * i, &g->m[i]->cap_seen);
-        if (r2 && !rc) rc = r2;
+        if (r2 && (!rc || (rc == BNR_ERR_SAMPLER_CAP && r2 != BNR_ERR_SAMPLER_CAP))) rc = r2;
+        else if (r2) g_err = msg_before;                     // keep the message of the status that is returned
     }
     if (next_row) *next_row = g->m[0]->next_row;
     return rc;

@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(512, 6) void k_gram8(const SRC chain_src, int s, in
 //               relative precision, G does not -- see the bound)
 //   k_gram_i8   T_l = X diag(d_l) X' EXACTLY in i32 (v_mfma_i32_16x16x64_i8; A = the byte mask of the j rows = -x, B = mask AND digits = x d of the
 //               i rows; |T_l| <= 128 kchunk), then G = - sum_l T_l 256^(L - 1 - l) 2^(e - 8 L + 2) by Horner in f64 (L roundings of relative size 2^-53).
-// Error against the exact Gram: 0 <= G_exact - G <= q 2^(e - 8 L + 2) <= 8 q 2^(-8 L) max_k S_k, and max |G| >= max_k S_k as soon as the column of the largest S
+// Error against the exact Gram (S rounded to nearest since round 6): |G_exact - G| <= q 2^(e - 8 L + 1) <= 4 q 2^(-8 L) max_k S_k, and max |G| >= max_k S_k as soon as the column of the largest S
 // has a one: relative to max |G| at most 8 q 2^(-8 L) -- L = 7 up to q = 9007 (5.6e-13 at q = 5050), L = 8 beyond (2e-14 at q = 45150): below 1e-12, the size of
 // the f64 path's own rounding.  Same tasks, K slices and partial-tile layout as k_gram8: the reduction in launch 0 of the factorization does not know the difference.
 // The loop (tools/gram_i8_lab.hip, profiles/round5_gram_i8.txt): X tiles staged through LDS in full 128-byte lines (direct 16-byte fragment loads were bound by
@@ -3257,10 +3257,20 @@ __global__ __launch_bounds__(1024) void k_sdigits(const SRC chain_src, int s)
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     const double *S = cd.trace + (size_t)P.prev * cd.rowlen + cd.o_S;
     __shared__ double red[16];
+    __shared__ int s_nonfinite;
+    if (tid == 0) s_nonfinite = 0;
     double m = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
     int k = tid;
     for (; k + 3072 < cd.q; k += 4096) { m = fmax(m, S[k]); m1 = fmax(m1, S[k + 1024]); m2 = fmax(m2, S[k + 2048]); m3 = fmax(m3, S[k + 3072]); }
     for (; k < cd.q; k += 1024) m = fmax(m, S[k]);
+    // a NaN or an infinite S_k: fmax drops the NaN and the fixed-point image of either is meaningless -- the f64 Gram would carry it into G + I and the factorization
+    // would report it; the same report from here.  Found from the partial maxima and the sum of the entries' differences, no second pass: x - x is 0 for every
+    // finite x and NaN for NaN and +-Inf
+    {
+        double z = 0.0;
+        for (int kk2 = tid; kk2 < cd.q; kk2 += 1024) { const double v = S[kk2]; z += v - v; }
+        if (!(z == 0.0)) atomicOr(&s_nonfinite, 1);
+    }
     m = fmax(fmax(m, m1), fmax(m2, m3));
     m = fmax(m, __shfl_xor(m, 32)); m = fmax(m, __shfl_xor(m, 16)); m = fmax(m, __shfl_xor(m, 8));
     m = fmax(m, __shfl_xor(m, 4)); m = fmax(m, __shfl_xor(m, 2)); m = fmax(m, __shfl_xor(m, 1));
@@ -3268,6 +3278,10 @@ __global__ __launch_bounds__(1024) void k_sdigits(const SRC chain_src, int s)
     __syncthreads();
     m = red[0];
     for (int w = 1; w < 16; ++w) m = fmax(m, red[w]);
+    if (s_nonfinite) {                                        // reported like a factorization that met a non-finite G + I (status 3, "G+I"); the digits below are then of no interest
+        if (tid == 0 && blockIdx.y == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[7], 1ull); }
+        m = 1.0;
+    }
     int e;
     (void)frexp(m, &e);                                       // m = f 2^e with f in [0.5, 1): every S_k < 2^e
     constexpr int BITS = 8 * L - 2;                           // S_k up < 2^BITS <= 2^62: the top digit stays below 64, a carry cannot overflow it
@@ -3277,7 +3291,7 @@ __global__ __launch_bounds__(1024) void k_sdigits(const SRC chain_src, int s)
     for (int idx = (int)blockIdx.y * 1024 + tid; idx < cd.kslab; idx += (int)gridDim.y * 1024) {
         const int ks = idx / cd.kcp, kk = idx % cd.kcp, k = ks * kchunk + kk;
         unsigned long long N = 0;
-        if (kk < kchunk && k < cd.q) N = (unsigned long long)(S[k] * up);
+        if (kk < kchunk && k < cd.q && !s_nonfinite) N = (unsigned long long)(S[k] * up + 0.5);     // rounded to nearest (the top digit has the headroom): |G_exact - G| <= q 2^(e - 8 L + 1), two-sided
         // balanced base-256 digits, least significant first: a byte >= 128 stands for byte - 256 and carries one into the next
         unsigned carry = 0;
 #pragma unroll

@@ -1257,6 +1257,51 @@ def test_device_reports_the_sampler_cap(gpu):
     ch.close()
 
 
+def test_group_reports_the_most_severe_member_status(gpu):
+    """bnr_group_run must not let a member's sampler cap (status 4, a warning to the callers: gibbs.jl's rejection loops never raise) hide another member's failed
+    factorization (status 3; the reference's `\\` of gibbs.jl:434 would throw) in the same call.  Member 1: zeta = NaN, update_theta!'s Gamma never accepts -> cap.  Member 2: an
+    infinite S in its first row -> G + I is not finite -> the factorization reports it.  Whichever order the members are in, the call returns 3."""
+    n, V, R = 40, 6, 2
+    X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=3)
+    for order in (0, 1):
+        capped = bnr_amd.Chain(X, y, R, 4, 11, 1, zeta=float("nan"))
+        broken = bnr_amd.Chain(X, y, R, 4, 11, 2)
+        for c in (capped, broken):
+            c.init_prior()
+        t = broken.fetch(1, 1)
+        t["S"][0, 3] = np.inf
+        broken.load(t, 1, 1)
+        g = bnr_amd.Group([capped, broken] if order == 0 else [broken, capped])
+        with pytest.raises(bnr_amd.BnrError) as e:
+            g.run(2, 2, 2)
+        assert e.value.code == 3 and "Cholesky" in str(e.value), (order, e.value.code, str(e.value))
+        assert capped.counters()["sampler_cap"] >= 1 and broken.counters()["chol_fail"] >= 1
+        g.close()
+        capped.close(); broken.close()
+
+
+def test_a_non_finite_S_is_reported_on_the_i8_gram_path_too(gpu):
+    """the fixed-point image of S that feeds the i8 Gram of a binary model matrix (k_sdigits) cannot carry a NaN or an infinity -- fmax drops the one, the conversion of
+    the other is undefined -- where the f64 Gram hands either to the factorization, which reports it (status 3, G + I).  Both paths must end the call the same way."""
+    n, V, R = 70, 12, 3
+    rng = np.random.default_rng(8)
+    X = bnr_amd.XInput(np.asfortranarray(rng.random((n, V * (V + 1) // 2)) < 0.5), False)
+    y = rng.normal(size=n)
+    for gram_i8 in (1, 0):
+        for bad in (np.nan, np.inf):
+            ch = bnr_amd.Chain(X, y, R, 4, 5, 1)
+            ch.set_option("gram_i8", gram_i8)
+            ch.init_prior()
+            t = ch.fetch(1, 1)
+            t["S"][0, 7] = bad
+            ch.load(t, 1, 1)
+            with pytest.raises(bnr_amd.BnrError) as e:
+                ch.run(2, 2, 2)
+            assert e.value.code == 3, (gram_i8, bad, e.value.code, str(e.value))
+            assert ch.counters()["chol_fail"] >= 1
+            ch.close()
+
+
 def test_post_burn_in_rows_match_the_oracle_at_config3(gpu):
     """Full-size parity AFTER burn-in (most xi = 0, S small, the Gram well conditioned -- another regime than the rows right after the
     prior draw): the 8 chains of BASELINE configs[2] run 2 000 sweeps as one lockstep group on the GPU, then the oracle continues from
