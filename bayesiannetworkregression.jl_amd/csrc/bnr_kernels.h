@@ -996,7 +996,7 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
 // two neighbours: without the rotation the eldest runs a task in 61 us, the second in 100, the youngest in 175, and the launch
 // ends with the youngest ones' half-done tasks on an otherwise idle chip.
 template <bool WT>
-__device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const double *Sp, double *Gpart, int t, int ti, int tj, int ks, double *sred, int rot = -1, int tid = -1, int rotmod = BNR_G8P_WPC)
+__device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const double *Sp, double *Gpart, int t, int ti, int tj, int ks, double *sred, int rot = -1, int tid = -1, int rotmod = BNR_G8P_WPC, unsigned long long *clk = nullptr)
 {
     constexpr int KG = 2, KB = 8;
     if (tid < 0) tid = threadIdx.x;
@@ -1058,6 +1058,10 @@ __device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const do
     BNR_G8_STORE(0);
     BNR_G8_LOAD(1);
     __syncthreads();
+#ifdef BNR_STAMPS
+    // both clocks around the K loop: shader cycles / 100 MHz ticks = the clock the PRODUCT kernel's loop runs at (tools/stamps_gram_clock.py)
+    if (clk && tid == 0) { clk[0] = __builtin_amdgcn_s_memtime(); clk[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 #define BNR_G8_BATCH_(B, DIAG)                                                                \
     do {                                                                                      \
         BNR_G8_COMPUTE((B) & 1, 0, DIAG);                                                     \
@@ -1103,6 +1107,9 @@ __device__ __forceinline__ void bnr_gram8_task(const bnr_gram_geom &cd, const do
             for (; b < be; ++b) BNR_G8_BATCH(b);
         }
     }
+#ifdef BNR_STAMPS
+    if (clk && tid == 0) { clk[2] = __builtin_amdgcn_s_memtime(); clk[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     // tile element (i,j) lives at [j*64 + i]; this lane: j = wj*32 + jt*16 + (lane>>4) + 4 r, i = wi*32 + it*16 + (lane&15)
     const int jb = wj * 32 + (lane >> 4), ib = wi * 32 + (lane & 15);
     if (kg == 1) {
@@ -1141,7 +1148,11 @@ __global__ __launch_bounds__(512, 6) void k_gram8(const SRC chain_src, int s, in
     const int ks = task >> 16;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     int tj = t - ti * (ti + 1) / 2;
+#ifdef BNR_STAMPS
+    bnr_gram8_task<false>(bnr_geom_of(cd), Sp, cd.Gpart, t, ti, tj, ks, sred, -1, -1, BNR_G8P_WPC, gslot < 256 ? cd.dbg + 2048 + 4 * gslot : nullptr);
+#else
     bnr_gram8_task<false>(bnr_geom_of(cd), Sp, cd.Gpart, t, ti, tj, ks, sred);
+#endif
     bnr_gram_count(cd, tj);
 }
 
@@ -1529,7 +1540,7 @@ __device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &
 // staged), every lane checks its own row and a wave vote says "all 64 rows there" -- which is the whole column, multipliers included.  The polls are bounded: a
 // column that never shows up (it cannot, short of a fault) ends the wait after BNR_PIPE_SPINS polls and reports the panel as failed.
 // Per element the updates arrive in column order except for the swap inside bnr_sweepN (k-2 before k-3): deterministic, independent of timing; NOT the summation
-// order of bnr_panel_sweep's MFMA mid update, so the factor differs from the round-5 build's in the last bits (rtol 1e-6 against the oracle is the bar).
+// order of bnr_panel_sweep's MFMA mid update, so the factor differs from the round-5 build's in the last bits (the parity bar is rtol 1e-6 against the CPU restatement of the reference, tests/).
 #define BNR_PIPE_SPINS (1 << 16)
 #ifndef BNR_PIPE_TIE
 #define BNR_PIPE_TIE 0      // 1: the publishing store tied to the block's last column instead of the next pivot (measured slower: one chain 172-174 against 168 us per sweep)

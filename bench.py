@@ -364,7 +364,7 @@ def main():
 
     # N = 1: one chain alone on the GPU (what every GPU does at N = 8; latency-bound).  N > 1: the weak-scaling figure, 8 chains on
     # EVERY GPU as one lockstep group.  Both continue from chain 1's data in the same process; reported as sub-records.
-    single, weak = None, None
+    single, weak, expected = None, None, None
     if C > 1 and world == 1:
         runner.close()
         runner = None
@@ -379,6 +379,33 @@ def main():
         dts = max_over_ranks(time.perf_counter() - t1)
         single = {"value": world * Ks / dts, "unit": "iterations/s", "chains_per_gpu": 1, "steps": Ks, "ms_per_step": 1e3 * dts / Ks}
         solo.close()
+        # What a SCALE record should be read against: the per-rank workload of the N-GPU layout -- the fit's chains sharded round-robin, total / N
+        # chains per GPU as one lockstep group -- timed HERE on one GPU, times N.  Ranks never exchange anything inside the timed region (one all-gather per
+        # convergence check, outside it), so N ranks of that workload are N copies of this measurement up to the slowest rank: a projection, not a measurement.
+        expected = {"1": {"chains_per_gpu": C, "it_per_s_all_chains": total_chains * K / dt, "measured": "this line's value"}}
+        for Nr in (2, 4, 8):
+            if total_chains % Nr or total_chains // Nr < 1:
+                continue
+            Cr = total_chains // Nr
+            if Cr == 1:
+                per_rank = Ks / dts
+            else:
+                sub = [bnr_amd.Chain.like(chains[0], a.seed, 2000 + 10 * Nr + i, Ks + 50) for i in range(Cr)]
+                for ch in sub:
+                    ch.init_prior()
+                sg = bnr_amd.Group(sub)
+                sg.prepare()
+                sg.run(2, 49, 49)
+                device_sync()
+                t1 = time.perf_counter()
+                sg.run(50, Ks + 49, Ks + 49)
+                device_sync()
+                per_rank = Cr * Ks / (time.perf_counter() - t1)
+                sg.close()
+                for ch in sub:
+                    ch.close()
+            expected[str(Nr)] = {"chains_per_gpu": Cr, "it_per_s_per_gpu": per_rank, "it_per_s_all_chains": Nr * per_rank,
+                                 "speedup_over_1_gpu": Nr * per_rank / (total_chains * K / dt), "measured": "per-rank workload on one GPU x %d" % Nr}
     elif world > 1 and a.chains_per_gpu == 0:
         if C > 1:
             runner.close()
@@ -452,7 +479,8 @@ def main():
                          "avg_launch_us_two_branch_schedule": gram_us_pipe,
                          "peak_measured_microbench": _measured_mfma_peak(),
                          "peak_measured_source": "profiles/round5_mfma_f64_peak.txt (tools/mfma_f64_peak.hip: pure v_mfma_f64_16x16x4_f64 loop, census-checked, median of the lines marked sustained); "
-                                                 "under the Gram's real load (LDS + global traffic beside the MFMAs) the shader clock falls from 2.36-2.39 to 2.10 GHz: profiles/round5_gram_lab2_ablation.txt"},
+                                                 "the product kernel's K loop holds 2.39 GHz (median over its workgroups after 2.5 s of back-to-back launches, both clocks stamped in the kernel: profiles/round6_gram_clock.txt) -- the 2.10 GHz of "
+                                                 "profiles/round5_gram_lab2_ablation.txt was a lab kernel's clock, not k_gram8's"},
             "max_rhat_gamma": None if rh is None else float(np.nanmax(rh[:q])), "max_rhat_xi": None if rh is None else float(np.nanmax(rh[q:])),
             "ess_gamma": None if ess is None else {"min": float(np.nanmin(ess[:q])), "median": float(np.nanmedian(ess[:q])),
                                                    "draws": int(nsamp * total_chains), "min_per_second": float(np.nanmin(ess[:q]) / dt)},
@@ -462,6 +490,8 @@ def main():
         }
         if single is not None:
             out["single_chain"] = single
+        if expected is not None:
+            out["expected_scaling"] = expected
         if weak is not None:
             out["weak_scaling"] = weak
         if not a.no_cpu_baseline and world == 1:            # the host-core baseline is taken at N = 1 only
