@@ -453,7 +453,9 @@ def main():
         value = total_chains * K / dt
         flops_gram = float(n) * n * q * C                         # algorithmic: symmetric X diag(S) X'  per chain of the launch
         traffic = None                                            # HBM bytes per k_gram launch from the PMC passes (tools/pmc_gram_round3.sh)
-        pmc_file = os.path.join(ROOT, "profiles", "round5_gram_pmc.json")
+        pmc_file = os.path.join(ROOT, "profiles", "round6_gram_pmc.json")
+        if not os.path.exists(pmc_file):
+            pmc_file = os.path.join(ROOT, "profiles", "round5_gram_pmc.json")
         if a.config == "cfg3" and C in (1, 8) and not a.binary_x and os.path.exists(pmc_file):
             traffic = json.load(open(pmc_file))["k_gram<bnr_one,2>" if C == 1 else "k_gram8<bnr_many>"].get("traffic_bytes_per_launch")
         achieved = flops_gram / (gram_us * 1e-6) / 1e12 if gram_us > 0 else 0.0
@@ -473,7 +475,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": ("k_sdigits + k_gram_i8 (X diag(S) X' of a 0/1 X: i8L exact v_mfma_i32_16x16x64_i8 Grams recombined in f64; achieved / frac are the f64-equivalent "
                                                       "algorithmic rate against the f64 peak, i.e. they may exceed 1)" if a.binary_x else "k_gram8 / k_gram (X diag(S) X', v_mfma_f64_16x16x4_f64)"), "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_source": "profiles/round5_gram_pmc.json (FETCH_SIZE x2 + WRITE_SIZE of a launch of this shape, separate --pmc passes, tools/round5_profiles.sh)",
+                         "traffic": traffic, "traffic_source": "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE of a launch of this shape, separate --pmc passes, tools/round6_profiles.sh / round5_profiles.sh)" % os.path.basename(pmc_file),
                          "sweep_frac": sweep_tflops / FP64_MFMA_PEAK_TFLOPS, "sweep_achieved": sweep_tflops, "sweep_flops_per_chain_iteration": f_iter,
                          "flops_per_launch": flops_gram, "avg_launch_us": gram_us, "launches_timed": gram_n,
                          "avg_launch_us_two_branch_schedule": gram_us_pipe,

@@ -256,7 +256,12 @@ int bnr_debug_set_exp(int32_t device, int32_t flags);
  *               for all members (k_xpass_group) when X has 8 MB or more per chain; 1: always; 0: one pass per member
  *   "split_sums" -1 (default): a chain run alone computes the back-projection's partial sums (update_theta!, update_Lambda!) in a launch of
  *               their own in front of the scalar tail, off the critical chain; 1: always; 0: inside the back-projection
- *   "spw_cap"   1..4 (default 4): super blocks per update workgroup of the factorization, at most (diagnostics)
+ *   "spw_cap"   1..4 (default 1 since round 6: one block each beside the pipelined panel sweep; rounds 3-5: 4): super blocks per update workgroup of the factorization, at most
+ *   "tail_after" / "node_after" (round 6): WHEN the scalar branch of a sweep (k_tail: theta, mu, Lambda, pi, the next tau2; k_node: tau2, u, xi; the X pass; k_rhs) starts
+ *               relative to the Gram / factorization branch it runs beside.  "tail_after" 0: k_tail of the previous sweep waits for the Gram; -1: it starts as soon as the
+ *               dispatcher lets it (rounds 1-5).  "node_after" p >= 0: k_node waits for launch number p of the factorization; -1: follows k_tail at once.  -2 (default):
+ *               chosen from a size model -- ordered where the factorization is the longer chain by a margin (n = 500, V = 100; n = 2000), free-running for small n or
+ *               large q.  Graph edges between the two branches; the tables do not depend on them.
  *   "wide_backproj" -1 (default): launches of the back-projection with 8 x CUs or more chunks of 32 edges (a lockstep group at large q) run k_backproj64 --
  *               a workgroup owns 64 edges, its drawing wave one edge per lane and the reference's own attempt loop (fewer instructions per edge; launches of one or
  *               two rounds of workgroups keep k_backproj, whose draws have the shorter latency); 1: always; 0: never.  Bitwise the same tables.

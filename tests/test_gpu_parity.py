@@ -1302,6 +1302,50 @@ def test_a_non_finite_S_is_reported_on_the_i8_gram_path_too(gpu):
             ch.close()
 
 
+def test_headline_size_posterior_summaries_match_the_cpu_restatement(gpu):
+    """Long-horizon pin at the HEADLINE size (until round 6 the only such check ran at n = 70): BASELINE configs[2]'s fit -- n=500, V=100, R=7, 8 chains,
+    seed 20240501 -- 1000 burn-in + 2000 kept sweeps per chain on the GPU as one lockstep group, against the same fit run by the CPU restatement of the reference
+    (tests/golden/headline_pin.npz, written by tests/golden/make_headline_pin.py; gibbs.jl:191-677).  Same seeds, same draw sites: the two sample paths coincide until
+    rounding flips a discrete draw somewhere, after which they are two runs of the same sampler -- so per chain P(xi_v = 1), the means of gamma on a fixed subset of 389
+    edges and the mean of tau2 must agree within 6 Monte-Carlo standard errors of their difference (batch means, 20 batches of 100 sweeps), and on average much closer."""
+    f = os.path.join(G, "headline_pin.npz")
+    pin = np.load(f)
+    n, V, R, seed, nburn, nsamp = (int(pin[k]) for k in ("n", "V", "R", "seed", "nburn", "nsamp"))
+    edges = pin["edges"]
+    X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=seed)
+    tot = nburn + nsamp + 1
+    chains = [bnr_amd.Chain(X, y, R, tot, seed, 1)]
+    chains += [bnr_amd.Chain.like(chains[0], seed, c, tot) for c in range(2, 9)]
+    for ch in chains:
+        ch.init_prior()
+    g = bnr_amd.Group(chains)
+    g.run(2, tot, tot)
+    nb = pin["xi_batch"].shape[1]
+    bs = nsamp // nb
+    zs, close = [], 0
+    for c, ch in enumerate(chains):
+        t = ch.fetch(nburn + 2, tot)
+        assert ch.counters()["chol_fail"] == 0
+        xi = t["xi"][:, :, 0]
+        ga = t["gamma"][:, :, 0][:, edges]
+        t2 = t["tau2"][:, 0, 0]
+        for name, mine, ref_mean, ref_batch in (("xi", xi, pin["xi_mean"][c], pin["xi_batch"][c]), ("gamma", ga, pin["gamma_mean"][c], pin["gamma_batch"][c]),
+                                                ("tau2", t2[:, None], pin["tau2_mean"][c:c + 1], pin["tau2_batch"][c][:, None])):
+            m = mine.mean(0)
+            mb = mine.reshape(nb, bs, -1).mean(1)
+            se = np.sqrt((mb.var(0, ddof=1) + ref_batch.var(0, ddof=1)) / nb) + 1e-12 + 1e-9 * np.abs(ref_mean)
+            z = np.abs(m - ref_mean) / se
+            assert np.all(z < 6.0), (c + 1, name, float(z.max()), int(z.argmax()))
+            zs.append(z)
+            close += int(np.sum(np.abs(m - ref_mean) <= 1e-6 * (1e-3 + np.abs(ref_mean))))
+    z = np.concatenate(zs)
+    assert np.mean(z) < 1.5, float(np.mean(z))                # (two independent runs would give E|z| = 0.8)
+    print("headline pin: %d summaries over 8 chains, max z %.2f, mean z %.2f, %d of them equal to 1e-6 (paths that never parted)" % (z.size, z.max(), z.mean(), close))
+    g.close()
+    for ch in chains:
+        ch.close()
+
+
 def test_post_burn_in_rows_match_the_oracle_at_config3(gpu):
     """Full-size parity AFTER burn-in (most xi = 0, S small, the Gram well conditioned -- another regime than the rows right after the
     prior draw): the 8 chains of BASELINE configs[2] run 2 000 sweeps as one lockstep group on the GPU, then the oracle continues from
