@@ -31,6 +31,6 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "headline_pin.npz"),
                         n=N, V=V, R=R, seed=SEED, nburn=NBURN, nsamp=NSAMP, edges=EDGES,
                         xi_mean=np.stack([r[0] for r in res]), gamma_mean=np.stack([r[1] for r in res]),
-                        xi_batch=np.stack([r[2] for r in res]), gamma_batch=np.stack([r[3] for r in res]),
-                        tau2_mean=np.array([r[4] for r in res]), tau2_batch=np.stack([r[5] for r in res]))
+                        xi_batch=np.stack([r[2] for r in res]).astype(np.float32), gamma_batch=np.stack([r[3] for r in res]).astype(np.float32),   # (batch means only feed the standard errors: float32)
+                        tau2_mean=np.array([r[4] for r in res]), tau2_batch=np.stack([r[5] for r in res]).astype(np.float32))
     print("written; P(xi = 1) over chains and nodes: min %.3f max %.3f" % (np.stack([r[0] for r in res]).min(), np.stack([r[0] for r in res]).max()))
