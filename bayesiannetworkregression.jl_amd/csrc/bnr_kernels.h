@@ -1589,6 +1589,12 @@ __device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &
 #ifndef BNR_PIPE_TIE
 #define BNR_PIPE_TIE 0      // 1: the publishing store tied to the block's last column instead of the next pivot (measured slower: one chain 172-174 against 168 us per sweep)
 #endif
+#ifndef BNR_PIPE_LATEPUB
+#define BNR_PIPE_LATEPUB 0      // 1: column j - 1 published behind the issue of pivot j's v_rsq_f64 (off the chain, but ~40 cycles later): tools/pipe_lab.hip 7 000 cycles per panel against 6 650
+#endif
+#ifndef BNR_PIPE_FASTHAND
+#define BNR_PIPE_FASTHAND 1
+#endif
 #ifndef BNR_PIPE_HEAVY
 #define BNR_PIPE_HEAVY 0    // 1: a starved wave polls with all ten reads instead of one (one chain 169.5 against 168.0 us per sweep)
 #endif
@@ -1616,6 +1622,11 @@ __device__ __forceinline__ int bnr_sweepN(double (&a)[N], int lane, unsigned pub
         if (j + 2 < N) s3 = bnr_readlane(a[j], COFF + j + 2);
         if (!(piv > 0.0)) bad = 1;
         double y = __builtin_amdgcn_rsq(piv);
+#if BNR_PIPE_LATEPUB
+        // column j - 1 goes to LDS here, right behind the issue of this pivot's v_rsq_f64 and named as its consumer: the store's issue slot sits inside the rsq's latency
+        // instead of between "next pivot known" and "its rsq issued" (measured: a publishing wave walks its pivots at ~155 cycles each, one that publishes nothing at ~118)
+        if (PUB == 2 && j >= 1) asm volatile("ds_write_b64 %1, %2 offset:%3" : "+v"(y) : "v"(pub_addr), "v"(lprev), "n"(512 * (j >= 1 ? j - 1 : 0)) : "memory");
+#endif
         if (j >= 1) {
 #pragma unroll
             for (int k = j + 2; k < N; ++k) tk[k] = bnr_readlane(lprev, COFF + k);
@@ -1626,10 +1637,17 @@ __device__ __forceinline__ int bnr_sweepN(double (&a)[N], int lane, unsigned pub
         piv = fma(-t1, t1, s1);
         double lj = a[j] * rinv;
         a[j] = lj;
+#if BNR_PIPE_LATEPUB
+        if (PUB == 2 && j == N - 1) asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(pub_addr), "v"(lj), "n"(512 * j) : "memory");
+#endif
         // (the store names a register of the sweep as an in/out operand: without such a tie the scheduler walks the whole pivot chain first and sinks all N stores behind
         // it -- the waves behind would see the columns only when this wave is done.  The last column of the block is the register: every pivot's lagged update touches it,
         // so the stores stay one per pivot and in order, but off the rsq chain; the next pivot itself for the last columns, which have no such update left)
-        if (PUB == 2) {
+#ifdef BNR_LAB_NOPUB          // (tools/pipe_lab.hip, timing only: the sweep without its publishing stores)
+        if (false) {
+#else
+        if (PUB == 2 && !BNR_PIPE_LATEPUB) {
+#endif
             if (BNR_PIPE_TIE && j + 3 < N) asm volatile("ds_write_b64 %1, %2 offset:%3" : "+v"(a[N - 1]) : "v"(pub_addr), "v"(lj), "n"(512 * j) : "memory");
             else asm volatile("ds_write_b64 %1, %2 offset:%3" : "+v"(piv) : "v"(pub_addr), "v"(lj), "n"(512 * j) : "memory");
         }
@@ -1646,6 +1664,9 @@ __device__ __forceinline__ int bnr_sweepN(double (&a)[N], int lane, unsigned pub
     }
     return bad;
 }
+#ifdef BNR_LAB_STAMPS
+__shared__ unsigned long long bnr_lab_stamp[8];
+#endif
 template <int W>
 __device__ __forceinline__ int bnr_pipe_wave(bnr_panelp_lds &sh, int lane, double *dst, size_t ld, unsigned long long *ph = nullptr)
 {
@@ -1718,6 +1739,68 @@ __device__ __forceinline__ int bnr_pipe_wave(bnr_panelp_lds &sh, int lane, doubl
 #else
 #define BNR_PIPE_TSTAMP() do { } while (0)
 #endif
+#if BNR_PIPE_FASTHAND
+    // The LAST pair of columns is the hand-over of the pivot chain to this wave: what starts this wave's first pivot is its own columns 0 and 1 only.  So the last pair is
+    // not fetched like the others (one poll round trip for "is it there", then a second one for the ten reads): the poll itself reads this lane's row of both columns and the
+    // multiplier pair of the own columns 0, 1 of each (four reads), the moment they are there columns 0, 1 are brought up to date and the pivot chain can start; the other six
+    // multiplier reads and their twelve multiply-adds follow beside its first pivot.
+#define BNR_PIPE_READ4(X0, X1, MA, MB, OFF)                                                                                                                  \
+    do { asm volatile("ds_read_b64 %0, %4 offset:%6\n\tds_read_b64 %1, %4 offset:%7\n\tds_read_b128 %2, %5 offset:%6\n\tds_read_b128 %3, %5 offset:%7"       \
+                 : "=&v"(X0), "=&v"(X1), "=&v"(MA), "=&v"(MB) : "v"(vcol), "v"(vmul), "n"(OFF), "n"((OFF) + 512) : "memory");                                \
+         asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])); } while (0)
+#define BNR_PIPE_WAIT4(X0, X1, MA, MB) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X0), "+v"(X1), "+v"(MA), "+v"(MB), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) :: "memory")
+#define BNR_PIPE_READ6(M, OFF)                                                                                                                               \
+    asm volatile("ds_read_b128 %0, %6 offset:%7\n\tds_read_b128 %1, %6 offset:%8\n\tds_read_b128 %2, %6 offset:%9\n\t"                                       \
+                 "ds_read_b128 %3, %6 offset:%10\n\tds_read_b128 %4, %6 offset:%11\n\tds_read_b128 %5, %6 offset:%12"                                        \
+                 : "=&v"(M[1]), "=&v"(M[2]), "=&v"(M[3]), "=&v"(M[5]), "=&v"(M[6]), "=&v"(M[7])                                                              \
+                 : "v"(vmul), "n"((OFF) + 16), "n"((OFF) + 32), "n"((OFF) + 48), "n"((OFF) + 528), "n"((OFF) + 544), "n"((OFF) + 560) : "memory")
+#define BNR_PIPE_WAIT6(M) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(M[1]), "+v"(M[2]), "+v"(M[3]), "+v"(M[5]), "+v"(M[6]), "+v"(M[7]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) :: "memory")
+    if (W > 0) {
+        // C0 / 2 trips: all but the last through the rolled two-trip loop (an even number of them) and, when their number is odd, one trip more in front of the last
+        constexpr int NT = C0 / 2, NLOOP = ((NT - 1) / 2) * 2;          // NT = 4, 8, 12: NLOOP = 2, 6, 10, then one plain trip, then the hand-over trip
+        BNR_PIPE_READ10(c0, c1, m, 0);
+#pragma unroll 1
+        for (int j = 0; j < 2 * NLOOP; j += 4) {
+            BNR_PIPE_TRIP(c0, c1, m, 0, n0, n1, mn, true);
+            BNR_PIPE_TRIP(n0, n1, mn, 1024, c0, c1, m, true);
+            vcol += 2048; vmul += 2048;
+        }
+        // trip NT - 2 (its pair is in flight in the first register set); the hand-over pair's four reads go out under its multiply-adds
+        BNR_PIPE_WAIT10(c0, c1, m);
+        if (!BNR_PIPE_HERE(c0, c1)) {
+            int spins = 0;
+            do {
+                if (++spins > BNR_PIPE_SPINS) { bad = 1; break; }
+                BNR_PIPE_POLL1(c1, 0);
+            } while (!__all(__double2hiint(c1) != BNR_PIPE_SENT_HI));
+            BNR_PIPE_READ10(c0, c1, m, 0);
+            BNR_PIPE_WAIT10(c0, c1, m);
+        }
+        BNR_PIPE_READ4(n0, n1, mn[0], mn[4], 1024);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = fma(-c0, m[c >> 1][c & 1], a[c]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = fma(-c1, m[4 + (c >> 1)][c & 1], a[c]);
+        // the hand-over trip
+        BNR_PIPE_WAIT4(n0, n1, mn[0], mn[4]);
+        if (!BNR_PIPE_HERE(n0, n1)) {
+            int spins = 0;
+            do {
+                if (++spins > BNR_PIPE_SPINS) { bad = 1; break; }
+                BNR_PIPE_READ4(n0, n1, mn[0], mn[4], 1024);
+                BNR_PIPE_WAIT4(n0, n1, mn[0], mn[4]);
+            } while (!BNR_PIPE_HERE(n0, n1));
+        }
+        BNR_PIPE_READ6(mn, 1024);
+        a[0] = fma(-n0, mn[0][0], a[0]); a[1] = fma(-n0, mn[0][1], a[1]);
+        a[0] = fma(-n1, mn[4][0], a[0]); a[1] = fma(-n1, mn[4][1], a[1]);
+        BNR_PIPE_WAIT6(mn);
+#pragma unroll
+        for (int c = 2; c < 8; ++c) a[c] = fma(-n0, mn[c >> 1][c & 1], a[c]);
+#pragma unroll
+        for (int c = 2; c < 8; ++c) a[c] = fma(-n1, mn[4 + (c >> 1)][c & 1], a[c]);
+    }
+#else
     if (W > 0) {
         BNR_PIPE_READ10(c0, c1, m, 0);
 #pragma unroll 1
@@ -1727,6 +1810,10 @@ __device__ __forceinline__ int bnr_pipe_wave(bnr_panelp_lds &sh, int lane, doubl
             vcol += 2048; vmul += 2048;
         }
     }
+#endif
+#ifdef BNR_LAB_STAMPS          // (tools/pipe_lab.hip: when this wave's own pivots start and end, two stamps per wave)
+    if (lane == 0) bnr_lab_stamp[2 * W] = __builtin_amdgcn_s_memtime();
+#endif
     if (W == 1) BNR_PPH(3);
     if (W == 3) BNR_PPH(6);
 #ifdef BNR_STAMPS
@@ -1738,6 +1825,9 @@ __device__ __forceinline__ int bnr_pipe_wave(bnr_panelp_lds &sh, int lane, doubl
     if (ph && lane == 0) { sh.st[W][20] = (unsigned long long)npoll; for (int i = 0; i < 24; ++i) ph[1024 + 24 * W + i] = sh.st[W][i]; }
 #endif
     (void)ntrip; (void)npoll;
+#ifdef BNR_LAB_STAMPS
+    if (lane == 0) bnr_lab_stamp[2 * W + 1] = __builtin_amdgcn_s_memtime();
+#endif
     if (W == 0) BNR_PPH(2);
     if (W == 1) BNR_PPH(4);
     if (W == 2) BNR_PPH(5);
@@ -1770,6 +1860,9 @@ __device__ __forceinline__ int bnr_panel_sweep_pipe(bnr_panelp_lds &sh, const bn
     __syncthreads();
 #ifdef BNR_STAMPS
     if (ph && tid == 0) ph[1] = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef BNR_LAB_W0_ONLY       // (tools/pipe_lab.hip, timing only: what the first wave's eight pivots cost with nobody reading beside it)
+    if (wave != 0) return 0;
 #endif
     if (wave == 0) return bnr_pipe_wave<0>(sh, lane, dst, ld, ph);
     if (wave == 1) return bnr_pipe_wave<1>(sh, lane, dst, ld, ph);
