@@ -2737,7 +2737,7 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
     const bnr_dev &cd = chain_src.get();
     extern __shared__ double su_lds[];           // R x V: u of this row (staged once for the q pass) -- where it fits the LDS budget (BNR_TAIL_U_LDS), else read from the row --, then bnr_tail_a's 4 R^2 + 8 doubles
     __shared__ double sred[3 * 16];
-    __shared__ double sll[3 * BNR_RMAX + 1], slam[BNR_RMAX], spi[3 * BNR_RMAX];
+    __shared__ double sll[3 * BNR_RMAX + 1], slam[BNR_RMAX], spi[3 * BNR_RMAX], spow[BNR_RMAX];
     __shared__ double sval[8];
     __shared__ int sflag[2];
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
@@ -2762,6 +2762,7 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
         __syncthreads();
     }
     if (tid < R) slam[tid] = row[cd.o_lam + tid];
+    if (tid >= BNR_TAIL_THREADS - 64 && tid - (BNR_TAIL_THREADS - 64) < R) spow[tid - (BNR_TAIL_THREADS - 64)] = pow((double)(tid - (BNR_TAIL_THREADS - 64) + 1), cd.eta);     // (r + 1)^eta of pi's Dirichlet parameters: a constant of the chain, evaluated beside the reductions instead of in front of pi's draws
     if (tid == 0) { sval[1] = row[ROW_MU]; sflag[0] = 0; sflag[1] = 0; }
     constexpr bool u_lds = ULDS;
     if (u_lds) for (int i = tid; i < R * V; i += blockDim.x) su_lds[i] = row[cd.o_u + i];
@@ -2830,6 +2831,29 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
     }
     bnr_wsync();
     double g_tau = 1.0;
+    if (wave == 0 && 3 * R + 2 <= 64) {
+        // ONE pass of the Gamma sampler for everything wave 0 draws: lanes 0 .. 3R-1 the variates of pi (gibbs.jl:620-636), lane 3R theta's (476-479), lane 3R+1 the NEXT
+        // tau2's (267-277) -- the same counters and shapes as one after the other (bitwise the same values), one walk through the sampler's code instead of two
+        const int t = lane;
+        const bool is_pi = (mask & 32) && t < 3 * R, th = t == 3 * R && (mask & 1), tn = t == 3 * R + 1 && (mask & 512);
+        double shp = 1.0; uint32_t it_ = P.it, site_ = SITE_PI, el_ = 0;
+        if (is_pi) {
+            const int r = t / 3, c = t % 3;
+            const double lam = slam[r], base = spow[r];
+            if (lam == 1.0) shp = (c == 0) ? base : (c == 1 ? 2.0 : 1.0);
+            else if (lam == 0.0) shp = (c == 0) ? base + 1.0 : 1.0;
+            else shp = (c == 0) ? base : (c == 1 ? 1.0 : 2.0);
+            el_ = (uint32_t)(3 * r + c);
+        } else if (th) { shp = cd.zeta + (V * (V + 1)) / 2.0; site_ = SITE_THETA; }
+        else if (tn) { shp = (n / 2.0) + (V * (V + 1) / 4.0); it_ = P.it + 1u; site_ = SITE_TAU2; }
+        double g = 1.0;
+        if (is_pi || th || tn) g = bnr_gamma(cd.seed, shp, it_, site_, el_, &cap);
+        if (is_pi) spi[t] = g;
+        if (th) row[ROW_THETA] = g * (2.0 / (2.0 * cd.iota + sll[0]));
+        g_tau = bnr_readlane_u(g, 3 * R + 1);
+        bnr_wsync();
+        if ((mask & 32) && t < 3 * R) { const int r = t / 3, c = t % 3; row[cd.o_pi + r + R * c] = spi[t] / (spi[3 * r] + spi[3 * r + 1] + spi[3 * r + 2]); }
+    } else
     if (wave == 0) {
         if (mask & (1 | 512)) {                                                   // theta (gibbs.jl:476-479) and the variate of the next tau2 (gibbs.jl:267-277)
             const bool th = lane == 0 && (mask & 1), tn = lane == 1 && (mask & 512);
@@ -2844,7 +2868,7 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
                 if (t < 3 * R) {
                     int r = t / 3, c = t % 3;
                     double lam = slam[r];
-                    double base = pow((double)(r + 1), cd.eta);
+                    double base = spow[r];
                     double alpha;
                     if (lam == 1.0) alpha = (c == 0) ? base : (c == 1 ? 2.0 : 1.0);
                     else if (lam == 0.0) alpha = (c == 0) ? base + 1.0 : 1.0;
