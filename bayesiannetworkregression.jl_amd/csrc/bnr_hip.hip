@@ -146,7 +146,7 @@ static void forget_alloc(bnr_chain *c, void *p)
 // process, after hipSetDevice, under a lock (handles may be created from several host threads); failures are reported at create.
 struct bnr_exec;
 static int late_kernels_lds_attributes(int bytes);
-static void launch_late_xpass_group2(bnr_exec &x, int s, unsigned grid, size_t lds, int tail_mask);
+static void launch_late_xpass_group2(bnr_exec &x, int s);
 static void launch_late_backproj64(bnr_exec &x, int s, int flags, size_t lds64);
 static int ensure_lds_attributes(int device)
 {
@@ -706,26 +706,21 @@ static bool group_shares_x(const bnr_exec &x)
         if (x.cds_pin[i].X != x.cds_pin[0].X || x.cds_pin[i].X8 != x.cds_pin[0].X8) return false;
     return true;
 }
-// tail_mask != 0 (a sweep): Delta and M of the same sweep (bnr_tail_a, k_tail's bits 2 | 4 | 256) ride in the same launch, one extra workgroup per chain in front of the grid
 static size_t tail_a_bytes(const bnr_exec &x) { return bnr_tail_a_lds_doubles(x.shape->R) * sizeof(double); }
-static void launch_xpass(bnr_exec &x, int s, int which, int tail_mask = 0)
+static void launch_xpass(bnr_exec &x, int s, int which)
 {
     // by default only where X is large (>= 8 MB per chain): the point is the L2 traffic beside the panel steps; small problems are chains of
     // latencies, and there the per-chain kernel's many small workgroups finish sooner (n = 200, V = 50: 125.8 vs 139.4 us per sweep of 8 chains)
     const bool big_x = (size_t)x.shape->n_pad * x.shape->q * sizeof(double) >= ((size_t)8 << 20);
-    const size_t lds_a = tail_mask ? tail_a_bytes(x) : 0;
     if (which == 3 && (x.group_xpass == 1 || (x.group_xpass < 0 && big_x)) && group_shares_x(x) && 16 * (size_t)x.shape->chunk_x * sizeof(double) <= 48 * 1024) {
         // one workgroup per column chunk and row slice for all members: X comes out of the L2s once, not once per chain
         // long column chunks (large q: 177 columns per workgroup at config 5): the straight-line column loop -- config 5 x 8 chains, where the scalar branch is the longer
         // chain behind the Gram; at the headline shape (32 columns per workgroup) it brought nothing per sweep (notes S), so short chunks keep the first kernel
-        const size_t lds = std::max(16 * x.shape->chunk_x * sizeof(double), lds_a);
-        const unsigned grid = (unsigned)(x.shape->nblk_x * ((x.shape->n_pad + 255) / 256) + (tail_mask ? x.nb : 0));
-        if (x.shape->chunk_x > 64) launch_late_xpass_group2(x, s, grid, lds, tail_mask);
-        else hipLaunchKernelGGL(k_xpass_group, dim3(grid), dim3(256), lds, x.stream, bnr_many{x.cds}, s, x.nb, tail_mask);
+        if (x.shape->chunk_x > 64) launch_late_xpass_group2(x, s);
+        else hipLaunchKernelGGL(k_xpass_group, dim3(x.shape->nblk_x * ((x.shape->n_pad + 255) / 256)), dim3(256), 16 * x.shape->chunk_x * sizeof(double), x.stream, bnr_many{x.cds}, s, x.nb);
         return;
     }
-    const size_t lds = std::max(3 * x.shape->chunk_x * sizeof(double), lds_a);
-    BNR_LAUNCH(k_xpass, dim3(round_up(x.shape->nblk_x, 8) * x.nb + (tail_mask ? round_up(x.nb, 8) : 0)), dim3(256), lds, x.stream, x, s, which, x.nb, tail_mask);
+    BNR_LAUNCH(k_xpass, dim3(round_up(x.shape->nblk_x, 8) * x.nb), dim3(256), 3 * x.shape->chunk_x * sizeof(double), x.stream, x, s, which, x.nb);
 }
 // Which factorization: right-looking (k_chol_step behind k_gram_reduce: the trailing update spread over the whole chip) unless the
 // caller asks for the left-looking one (k_chol_ll: no reduction pass, ceil(nbk/4) + nbk - 1 workgroups per chain and launch, can
@@ -951,17 +946,17 @@ static void launch_backproj(bnr_exec &x, int s, int flags)
     const int wide = (x.nb == 1 || x.shape->nblk_bp >= 1024) ? 256 : 0;    // four columns of X per wave and trip (see the kernel)
     BNR_LAUNCH(k_backproj, dim3(round_up(x.shape->nblk_bp, 8) * x.nb), dim3(256), lds, x.stream, x, s, flags | wide, x.nb, nslot);
 }
-static void launch_tail(bnr_exec &x, int s, int mask, int xg_src)
+static void launch_tail(bnr_exec &x, int s, int mask, int xg_src, unsigned wgs = 1)
 {
 #ifdef BNR_EXP_PAD
-    { static const int pad = getenv("BNR_EXP_TAIL_PAD_US") ? atoi(getenv("BNR_EXP_TAIL_PAD_US")) : 0; if (mask == (1023 & ~BNR_TAIL_EARLY)) xg_src |= pad << 8; }
+    { static const int pad = getenv("BNR_EXP_TAIL_PAD_US") ? atoi(getenv("BNR_EXP_TAIL_PAD_US")) : 0; if (mask == 1023) xg_src |= pad << 8; }
 #endif
     const size_t rv = (size_t)x.shape->R * x.shape->V;
     const size_t lds_a = (mask & BNR_TAIL_EARLY) ? tail_a_bytes(x) : 0;       // Delta / M / inv(M) asked for here (hooks, a loaded row): bnr_tail_a's work matrices behind u
-    if (rv <= BNR_TAIL_U_LDS) { BNR_LAUNCH(k_tail, dim3(1, 1, x.nb), dim3(BNR_TAIL_THREADS), rv * sizeof(double) + lds_a, x.stream, x, s, mask, xg_src); return; }
+    if (rv <= BNR_TAIL_U_LDS) { BNR_LAUNCH(k_tail, dim3(wgs, 1, x.nb), dim3(BNR_TAIL_THREADS), rv * sizeof(double) + lds_a, x.stream, x, s, mask, xg_src); return; }
     // u beyond the LDS budget: the instantiation that reads it from the table row
-    if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tail<bnr_one, false>), dim3(1, 1, 1), dim3(BNR_TAIL_THREADS), lds_a, x.stream, bnr_one{*x.shape}, s, mask, xg_src);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tail<bnr_many, false>), dim3(1, 1, x.nb), dim3(BNR_TAIL_THREADS), lds_a, x.stream, bnr_many{x.cds}, s, mask, xg_src);
+    if (x.nb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tail<bnr_one, false>), dim3(wgs, 1, 1), dim3(BNR_TAIL_THREADS), lds_a, x.stream, bnr_one{*x.shape}, s, mask, xg_src);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tail<bnr_many, false>), dim3(wgs, 1, x.nb), dim3(BNR_TAIL_THREADS), lds_a, x.stream, bnr_many{x.cds}, s, mask, xg_src);
 }
 // The scalar tail of sweep s with everything it needs: with split_sums the per-block partial sums of update_theta! / update_Lambda!
 // (gibbs.jl:476, 603-605) are not computed by the back-projection on the critical chain but by a launch of their own in front of the tail --
@@ -974,7 +969,7 @@ static bool split_sums(const bnr_exec &x) { return x.split_sums == 1 || (x.split
 static void launch_full_tail(bnr_exec &x, int s)
 {
     if (split_sums(x)) launch_backproj(x, s, 4);
-    launch_tail(x, s, 1023 & ~BNR_TAIL_EARLY, 0);           // (Delta, M, inv(M) of sweep s ran beside its X pass: launch_sweep)
+    launch_tail(x, s, 1023, 0, 2);                          // two workgroups per chain: Delta, M, inv(M) (workgroup 1) beside the rest (workgroup 0)
 }
 static hipEvent_t next_event(bnr_exec &x)
 {
@@ -1020,7 +1015,7 @@ static void launch_sweep(bnr_exec &x, int s, bool prev_tail)
     } else
     if (prev_tail) launch_full_tail(x, s - 1);
     launch_node(x, s, 3);
-    launch_xpass(x, s, 3, BNR_TAIL_EARLY);
+    launch_xpass(x, s, 3);
     launch_rhs(x, s);
     if (overlap) { for (hipEvent_t e : ej) if (e) HIPNOTE(hipStreamWaitEvent(x.stream, e, 0)); }
     else { launch_gram(x, s, sb, timed); launch_chol(x, s, sb); }
@@ -2321,8 +2316,8 @@ static int late_kernels_lds_attributes(int bytes)
     for (const void *f : tails) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     return BNR_OK;
 }
-static void launch_late_xpass_group2(bnr_exec &x, int s, unsigned grid, size_t lds, int tail_mask)
-{ hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xpass_group2<0>), dim3(grid), dim3(256), lds, x.stream, bnr_many{x.cds}, s, x.nb, tail_mask); }
+static void launch_late_xpass_group2(bnr_exec &x, int s)
+{ hipLaunchKernelGGL(HIP_KERNEL_NAME(k_xpass_group2<0>), dim3(x.shape->nblk_x * ((x.shape->n_pad + 255) / 256)), dim3(256), 16 * x.shape->chunk_x * sizeof(double), x.stream, bnr_many{x.cds}, s, x.nb); }
 static void launch_late_backproj64(bnr_exec &x, int s, int flags, size_t lds64)
 { BNR_LAUNCH(k_backproj64, dim3(round_up((x.shape->nblk_bp + 1) / 2, 8) * x.nb), dim3(256), lds64, x.stream, x, s, flags, x.nb); }
 }

@@ -478,18 +478,21 @@ __device__ inline void wave_tri_inverse(const double *A, double *T, int R, int l
 
 
 // ===================================================================================== the early part of the scalar tail: Delta and M (gibbs.jl:496-499, 516-548)
-// update_Delta! needs xi, update_M! needs u and xi: both are k_node's output of THIS sweep, not the back-projection's.  Round 6: in a sweep they no longer wait
-// for the back-projection in k_tail (one workgroup per chain on the scalar branch, 32 us alone / 58 us beside the Gram's drain, of which this part is 20) but run as ONE
-// extra workgroup per chain inside the launch of the X pass that follows k_node (k_xpass / k_xpass_group / k_xpass_group2, tail_mask != 0: the first workgroups of the
-// grid), i.e. beside it, off every chain of dependencies -- the draws are keyed by (iteration, site, element), so when they are evaluated changes nothing.
-// The same function serves k_tail (the hooks bnr_update_Delta / bnr_update_M, and inv(M) / logdet M for a row that was loaded or initialised).
+// update_Delta! needs xi, update_M! needs u and xi: k_node's output of the sweep, not the back-projection's; and nothing in the rest of the tail needs THEM.  Round 6: in a sweep
+// they are no longer a phase of k_tail's one workgroup per chain (32 us alone / 58 us beside the Gram's drain, of which this part was 12-20) but a SECOND workgroup of the same
+// launch (k_tail, blockIdx.x == 1) that runs beside the first on another CU.  (First cut of the round: one extra workgroup per chain in the launch of the X pass that follows
+// k_node -- it hid the work completely for a group, but a chain alone got a 24 us X pass instead of 13: its serial 18 us workgroup was the launch's long pole.)
+// The draws are keyed by (iteration, site, element): bitwise the values of rounds 1-5.
 //   mask bits: 2 Delta, 4 M, 256 inv(M) and logdet M for the next k_node (cd.Minv).
 //   Called by EVERY thread of a workgroup of >= 256 threads (block barriers inside); threads 256.. only take part in the barriers.
 //   lds: 4 R^2 + 8 doubles.
 #define BNR_TAIL_EARLY (2 | 4 | 256)
 __host__ __device__ inline size_t bnr_tail_a_lds_doubles(int R) { return (size_t)4 * R * R + 8; }
-__device__ __forceinline__ void bnr_tail_a(const bnr_dev &cd, const bnr_plan_entry P, int mask, double *lds, int tid)
+__device__ __forceinline__ void bnr_tail_a(const bnr_dev &cd, const bnr_plan_entry P, int mask, double *lds, int tid, bool mirror = false)
 {
+    // mirror: this is workgroup 1 of a sweep's two-workgroup launch and the row is being copied to the head of the table by workgroup 0 at the same time (purge ring,
+    // gibbs.jl:857-860): workgroup 0 leaves Delta and M out of its copy, they are written to the copies from here
+    double *ring0 = (mirror && (P.wrap & 1) && P.row != 0) ? cd.trace : nullptr, *ring1 = (mirror && (P.wrap & 1) && (P.wrap & 4)) ? cd.trace + cd.rowlen : nullptr;
     const int R = cd.R, V = cd.V, RR = R * R;
     double *sPsi = lds, *sA = lds + RR, *sT = lds + 2 * RR, *sBm = lds + 3 * RR, *sredA = lds + 4 * RR;     // sredA: 2 x 4 wave partials
     const bool act = tid < 256;
@@ -538,6 +541,8 @@ __device__ __forceinline__ void bnr_tail_a(const bnr_dev &cd, const bnr_plan_ent
             else if (b > 0.0) out = 0.0;
             else { double ua, ub; bnr_draw2(cd.seed, P.it, SITE_DELTA_COIN, 0, 0, ua, ub); out = (ua < 0.5) ? 0.0 : 1.0; }
             row[ROW_DELTA] = out;
+            if (ring0) ring0[ROW_DELTA] = out;
+            if (ring1) ring1[ROW_DELTA] = out;
         }
     }
     if (act && wave == 1 && (mask & 4)) {                                        // Bartlett diagonal: chi-square draws
@@ -578,6 +583,8 @@ __device__ __forceinline__ void bnr_tail_a(const bnr_dev &cd, const bnr_plan_ent
                 double sacc = 0.0;
                 for (int k = 0; k < R; ++k) sacc += sPsi[a + R * k] * sPsi[b + R * k];
                 row[cd.o_M + idx] = sacc;
+                if (ring0) ring0[cd.o_M + idx] = sacc;
+                if (ring1) ring1[cd.o_M + idx] = sacc;
                 sBm[idx] = sacc;
             }
         } else {
@@ -611,21 +618,11 @@ __device__ __forceinline__ void bnr_tail_a(const bnr_dev &cd, const bnr_plan_ent
 //   PW[b][i] = sum_{e in chunk} X[i,e] W_e ;  PA[b][i] = sum X[i,e] sz_e                 (gibbs.jl:432-433)
 // which: bit0 -> W/PW, bit1 -> sz/PA, bit2 -> PG = partial X*gamma(row `P.prev` if bit3 else row P.row)
 template <class SRC>
-__global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int which, int nchains, int tail_mask)
+__global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int which, int nchains)
 {
-    // 1-D grid = [round_up(chains, 8) when tail_mask != 0] + round_up(blocks, 8) x chains, decoded like k_gram / k_backproj (chains that read
-    // the same columns of X are neighbours on one XCD)
+    // 1-D grid = round_up(blocks, 8) x chains, decoded like k_gram / k_backproj (chains that read the same columns of X are neighbours on one XCD)
     extern __shared__ double sh[];
-    int gid = blockIdx.x;
-    if (tail_mask) {
-        // the first workgroups of the grid: Delta and M of this sweep, one workgroup per chain, beside the pass (bnr_tail_a)
-        const int nfront = (nchains + 7) & ~7;
-        if (gid < nfront) {
-            if (gid < nchains) { const bnr_dev &ct = chain_src.at(gid); bnr_tail_a(ct, ct.plan[ct.pbase[0] + s], tail_mask, sh, threadIdx.x); }
-            return;
-        }
-        gid -= nfront;
-    }
+    const int gid = blockIdx.x;
     const int gx = gid & 7, gr = gid >> 3;
     const int bid = (gr / nchains) * 8 + gx;
     const bnr_dev &cd = chain_src.at(gr % nchains);
@@ -678,15 +675,11 @@ __global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int w
 // bytes from the L2s, and the factorization's panel steps that run beside this kernel keep their memory latency (a dependent launch
 // beside a streaming kernel: 21 us instead of 6.6, tools/interfere_probe.hip).  which = 3 only (W and sqrt(S) z1).
 //   grid = nblk_x x ceil(n_pad / 256), 256 threads, dynamic LDS = 2 x 8 x chunk_x doubles.
-__global__ __launch_bounds__(256) void k_xpass_group(const bnr_many chain_src, int s, int nchains, int tail_mask)
+__global__ __launch_bounds__(256) void k_xpass_group(const bnr_many chain_src, int s, int nchains)
 {
     if (BNR_EXP_SKIP_SCALAR()) return;
     extern __shared__ double sh[];
-    int wg = blockIdx.x;
-    if (tail_mask) {                                       // the first nchains workgroups: Delta and M of this sweep beside the pass (bnr_tail_a)
-        if (wg < nchains) { const bnr_dev &ct = chain_src.at(wg); bnr_tail_a(ct, ct.plan[ct.pbase[0] + s], tail_mask, sh, threadIdx.x); return; }
-        wg -= nchains;
-    }
+    const int wg = blockIdx.x;
     const bnr_dev &c0 = chain_src.at(0);                  // the geometry and the shared X, index maps
     const int rs = (c0.n_pad + 255) / 256, bid = wg / rs, slice = wg % rs, tid = threadIdx.x;
     const int chunk = c0.chunk_x, e0 = bid * chunk, ne = min(chunk, c0.q - e0), R = c0.R;
@@ -2719,8 +2712,8 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
 // When a bit is clear the value already in `row` is kept.
 // xg_src: 0 = cd.xg (from k_solve_gemv); 1 = sum of the PG partials (X*gamma by k_xpass bit2).
 // Independent scalar draws sit on different wavefronts so that their long scalar sampler code runs concurrently.
-// Round 6: in a sweep this kernel runs with the bits 1 | 8 | 16 | 32 | 64 | 128 | 512 only -- what needs the back-projection's output; Delta, M and inv(M) (bits 2, 4, 256:
-// bnr_tail_a above) have been computed beside the X pass of the same sweep by then.  With those bits set (the hooks, a loaded or initialised row) bnr_tail_a runs here first.
+// Round 6: in a sweep the launch has TWO workgroups per chain (grid.x = 2): workgroup 0 runs the bits 1 | 8 | 16 | 32 | 64 | 128 | 512 -- what needs the back-projection's
+// output --, workgroup 1 Delta, M and inv(M) (bits 2, 4, 256: bnr_tail_a above) beside it.  With grid.x = 1 (the hooks, a loaded or initialised row) bnr_tail_a runs here first.
 
 #define BNR_TAIL_U_LDS 15360     // doubles of u (R x V) that k_tail stages in LDS (120 KB); a larger u is read from the trace row (same values, same order of operations)
 #define BNR_TAIL_THREADS 512   // 8 wavefronts: the seven role waves of phase 3 + one; two per SIMD, so the kernel may use 256 vector registers (no spills: with
@@ -2756,7 +2749,11 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
 #define BNR_TSTAMP(slot) do { } while (0)
 #endif
     BNR_TSTAMP(0);
-    if (mask & BNR_TAIL_EARLY) {                   // Delta, M, inv(M): only outside a sweep (hooks, refresh) -- in a sweep the X pass's launch has done them
+    if (gridDim.x == 2) {
+        // a sweep's launch: workgroup 1 of the chain does Delta, M, inv(M) (what needs only k_node's output), workgroup 0 the rest, side by side
+        if (blockIdx.x == 1) { if (mask & BNR_TAIL_EARLY) bnr_tail_a(cd, P, mask, su_lds, tid, (mask & 128) != 0); return; }
+        mask &= ~BNR_TAIL_EARLY;
+    } else if (mask & BNR_TAIL_EARLY) {            // one workgroup for everything (hooks, a loaded or initialised row): the early part first
         bnr_tail_a(cd, P, mask, su_lds + (ULDS ? (size_t)R * V : 0), tid);
         if (!(mask & ~BNR_TAIL_EARLY)) return;
         __syncthreads();
@@ -2932,10 +2929,13 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
     if ((mask & 128) && (P.wrap & 1)) {
         __syncthreads();
         double *dst = cd.trace;
-        if (row != dst) for (int i = tid; i < cd.rowlen; i += blockDim.x) dst[i] = row[i];
+        // (two workgroups per chain: Delta and M of this row are being written by workgroup 1 right now -- it writes them to the copies itself, they are left out here)
+        const bool two = gridDim.x == 2;
+        const int m0 = cd.o_M, m1 = cd.o_M + R * R;
+        if (row != dst) for (int i = tid; i < cd.rowlen; i += blockDim.x) if (!two || !(i == ROW_DELTA || (i >= m0 && i < m1))) dst[i] = row[i];
         if (P.wrap & 4) {                        // purge_burn == 1: the state sits in the hidden scratch row, rows 1 AND 2 get it
             double *dst2 = cd.trace + cd.rowlen;
-            for (int i = tid; i < cd.rowlen; i += blockDim.x) dst2[i] = row[i];
+            for (int i = tid; i < cd.rowlen; i += blockDim.x) if (!two || !(i == ROW_DELTA || (i >= m0 && i < m1))) dst2[i] = row[i];
         }
     }
     BNR_TSTAMP(6);
@@ -3270,15 +3270,11 @@ __device__ __forceinline__ void bnr_xg_dispatch(int nc, const XT *xp, size_t ld,
     }
 }
 template <int LATE>     // (a template only so that the kernel is emitted behind the others, with the instantiations: see the note above)
-__global__ __launch_bounds__(256) void k_xpass_group2(const bnr_many chain_src, int s, int nchains, int tail_mask)
+__global__ __launch_bounds__(256) void k_xpass_group2(const bnr_many chain_src, int s, int nchains)
 {
     if (BNR_EXP_SKIP_SCALAR()) return;
     extern __shared__ double sh[];
-    int wg = blockIdx.x;
-    if (tail_mask) {                                       // the first nchains workgroups: Delta and M of this sweep beside the pass (bnr_tail_a)
-        if (wg < nchains) { const bnr_dev &ct = chain_src.at(wg); bnr_tail_a(ct, ct.plan[ct.pbase[0] + s], tail_mask, sh, threadIdx.x); return; }
-        wg -= nchains;
-    }
+    const int wg = blockIdx.x;
     const bnr_dev &c0 = chain_src.at(0);                  // the geometry and the shared X, index maps
     const int rs = (c0.n_pad + 255) / 256, bid = wg / rs, slice = wg % rs, tid = threadIdx.x;
     const int chunk = c0.chunk_x, e0 = bid * chunk, ne = min(chunk, c0.q - e0), R = c0.R;
