@@ -921,7 +921,9 @@ static int node_after_default(const bnr_exec &x)
     // k_node starts when what is left of the factorization is about k_node + X pass + k_rhs long (+ 20 us), at most a quarter into it
     const double per = fact_est_us(x) / chol_launches(x);
     const int p = (int)((fact_est_us(x) - (scalar_est_us(x) - 20.0) - 20.0) / per);
-    return std::max(0, std::min(p, chol_launches(x) / 4));
+    // (a group's scalar branch is the longer one -- k_tail 20-36 us beside launch 0, k_node 25, X pass 24-37, k_rhs 10 --: an eighth into the factorization, a chain alone a quarter;
+    // measured per sweep of 8 chains with k_node behind launch 2 / 3 / 4 / 5 / 6: 367.2 / 368.1 / 368.6 / 374.7 / 383.0 us, one chain 4 / 5 / 6 / 7 / 8: 166.9 / 166.4 / 166.4 / 167.7 / 174.9)
+    return std::max(0, std::min(p, chol_launches(x) / (x.nb > 1 ? 8 : 4)));
 }
 static int tail_after(const bnr_exec &x) { return x.tail_after == -2 ? tail_after_default(x) : x.tail_after; }
 static int node_after(const bnr_exec &x) { const int v = x.node_after == -2 ? node_after_default(x) : x.node_after; return std::min(v, chol_launches(x) - 1); }

@@ -10,7 +10,15 @@ def from_csv(path):
     out = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            out.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+            name = r["Kernel_Name"]
+            # the Gram kernels are launched for lockstep groups of different sizes in one bench.py run (the 8-chain headline group, the 4- and 2-chain per-rank workloads of
+            # `expected_scaling`): one row per launch size, so that the headline launch's average can be read off (round 6)
+            if "k_gram" in name and "reduce" not in name:
+                g = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)
+                w = int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 0)) or 0)
+                if g and w:
+                    name = "[%d wgs] %s" % (g // w, name.replace("void ", ""))
+            out.append((name, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
     return out
 
 def main(d):
@@ -28,6 +36,9 @@ def main(d):
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print("%-52s %8d %12.2f %10.2f %10.2f %6.1f%%" % (name[:52], a[0], a[1] / a[0] / 1e3, a[2] / 1e3, a[3] / 1e3, 100.0 * a[1] / tot))
     print("total kernel time: %.3f ms over %d dispatches" % (tot / 1e6, sum(a[0] for a in agg.values())))
+    if any(k.startswith("[") for k in agg):
+        print("(rows marked [N wgs]: the Gram kernels by launch size -- a bench.py run times the headline group of 8 chains, then one chain and the 4- and 2-chain per-rank workloads of "
+              "`expected_scaling`; the other <bnr_many> rows average over those group sizes: headline-only figures are in the sweep statistics / DESIGN.md section 4)")
 
 if __name__ == "__main__":
     main(sys.argv[1])
