@@ -407,8 +407,10 @@ __global__ __launch_bounds__(64) void k_node(const SRC chain_src, int s, int mod
         if (lane == 0) row[cd.o_xi + k] = NAN;
         return;
     }
+    // (the R logarithms side by side in R lanes, then added in the order of i: the same sum as one after the other in every lane, a seventh of the dependent log evaluations at R = 7)
+    const double lgS = (lane < R) ? 2.0 * log(sL[lane + R * lane]) : 0.0;
     double ldS = 0.0;
-    for (int i = 0; i < R; ++i) ldS += 2.0 * log(sL[i + R * i]);
+    for (int i = 0; i < R; ++i) ldS += bnr_readlane_u(lgS, i);
     // b = c / tau2 ; mu_t = Sigma b (gibbs.jl:364)
     double b = (lane < R) ? sc[lane] / tau2 : 0.0;
     double mt = wave_fwd_solve(sL, R, lane, b);
@@ -596,8 +598,9 @@ __device__ __forceinline__ void bnr_tail_a(const bnr_dev &cd, const bnr_plan_ent
             for (int idx = lane; idx < RR; idx += 64) sA[idx] = sBm[idx];
             int f = wave_chol(sA, R, lane);
             if (f && lane == 0) { atomicAdd((unsigned long long *)&cd.counters[3], 1ull); atomicAdd((unsigned long long *)&cd.counters[6], 1ull); }
+            const double lgm = (lane < R) ? 2.0 * log(sA[lane + R * lane]) : 0.0;      // (side by side, added in the order of i: see k_node)
             double ldm = 0.0;
-            for (int i = 0; i < R; ++i) ldm += 2.0 * log(sA[i + R * i]);
+            for (int i = 0; i < R; ++i) ldm += bnr_readlane_u(lgm, i);
             wave_tri_inverse(sA, sT, R, lane);                                    // Linv (lower)
             for (int idx = lane; idx < RR; idx += 64) {
                 int a = idx % R, b = idx / R, k0 = a > b ? a : b;
