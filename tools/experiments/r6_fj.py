@@ -1,6 +1,6 @@
 """flag_join = 1 (the sweep's join as a flag polled by k_solve_w, the critical chain on one queue) against the graph-edge join: bitwise the same tables."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, bnr_amd
 for (n, V, R, C, tot) in [(193, 30, 5, 1, 40), (500, 40, 4, 3, 30), (500, 100, 7, 8, 40), (500, 100, 7, 1, 60), (70, 19, 5, 2, 50), (200, 50, 5, 1, 80)]:
     X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=7)

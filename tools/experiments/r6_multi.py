@@ -1,7 +1,7 @@
 """chol_multi = 1 (k_chol_steps: several panel steps per launch, barrier among the chain's workgroups on their XCD) against the launch-per-step factorization: bitwise the same
 tables (same arithmetic, same order), alone and in groups of 3 and 8; then us per sweep."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, bnr_amd
 for (n, V, R, C) in [(193, 30, 5, 1), (500, 40, 4, 3), (500, 100, 7, 8), (500, 100, 7, 1), (130, 12, 3, 2), (320, 20, 3, 5)]:
     X, y, _ = bnr_amd.make_synthetic(n, V, R, seed=7)

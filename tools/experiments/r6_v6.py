@@ -1,6 +1,6 @@
 """factor_variant 6 (k_chol_step2p: two panels per launch, eight-wave pipeline) against the one-panel pipeline: tables to rounding, alone and in a group; then timings."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, bnr_amd
 worst = 0.0
 for (n, V, R) in [(70, 19, 5), (193, 30, 5), (64, 9, 2), (500, 40, 4), (500, 100, 7), (130, 12, 3)]:
