@@ -269,6 +269,17 @@ __device__ __forceinline__ double edge_W(const double *u, const double *lam, int
 // The V-1 other nodes are staged through LDS in chunks of 64 (one per lane: U_a = u_a .* lambda, V_a = U_a / h_a,
 // g_a / h_a), then lane p accumulates the p-th of the R(R+1)/2 + R sums sequentially over a (the reference's order).
 #define BNR_NODE_MAXSUM 9      // ceil((32*33/2 + 32) / 64)
+// (-DBNR_STAMPS, tools/stamps_timeline.py) a sweep's kernels on one clock: per kind 4 slots from dbg[4000]: s_memrealtime (100 MHz, the same on every XCD) at the entry of
+// workgroup 0, the latest entry of any workgroup, the latest exit of any workgroup's thread 0.  atomicMax: what is read back belongs to the last sweep that ran.
+#ifdef BNR_STAMPS
+#define BNR_TL_IN(cd, kind, first) do { if (threadIdx.x == 0) { const unsigned long long rt_ = __builtin_amdgcn_s_memrealtime(); if (first) (cd).dbg[4000 + 4 * (kind)] = rt_; \
+                                         atomicMax((unsigned long long *)&(cd).dbg[4000 + 4 * (kind) + 1], rt_); } } while (0)
+#define BNR_TL_OUT(cd, kind) do { if (threadIdx.x == 0) atomicMax((unsigned long long *)&(cd).dbg[4000 + 4 * (kind) + 2], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#else
+#define BNR_TL_IN(cd, kind, first) do { } while (0)
+#define BNR_TL_OUT(cd, kind) do { } while (0)
+#endif
+enum { TL_GRAM = 0, TL_SOLVE_W, TL_SOLVE_A4, TL_BACKPROJ, TL_PSUM, TL_TAIL, TL_TAIL_A, TL_NODE, TL_XPASS, TL_RHS, TL_SDIGITS, TL_KINDS };
 template <class SRC>
 __global__ __launch_bounds__(64) void k_node(const SRC chain_src, int s, int mode)
 {
@@ -292,6 +303,7 @@ __global__ __launch_bounds__(64) void k_node(const SRC chain_src, int s, int mod
         cd.dbg[2000 + 4 * k] = __builtin_amdgcn_s_memrealtime(); cd.dbg[2000 + 4 * k + 3] = (v & 7u) | ((unsigned long long)h << 8);
     }
 #endif
+    BNR_TL_IN(cd, TL_NODE, k == 0);
     int cap = 0;
     double tau2;
     if (mode & 1) {
@@ -437,6 +449,7 @@ __global__ __launch_bounds__(64) void k_node(const SRC chain_src, int s, int mod
 #ifdef BNR_STAMPS
     if (lane == 0 && k < 256) cd.dbg[2000 + 4 * k + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
+    BNR_TL_OUT(cd, TL_NODE);
 }
 
 // in-place lower Cholesky of an LDS matrix by ONE wavefront (all 64 lanes call); returns 0 ok / 1 not positive definite
@@ -631,6 +644,7 @@ __global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int w
     const bnr_dev &cd = chain_src.at(gr % nchains);
     if (bid >= cd.nblk_x) return;
     if (BNR_EXP_SKIP_SCALAR() && which == 3) return;
+    BNR_TL_IN(cd, TL_XPASS, bid == 0);
     double *sW = sh, *sZ = sh + cd.chunk_x, *sG = sh + 2 * cd.chunk_x;
     const bnr_plan_entry P = cd.plan[cd.pbase[0] + s];
     const double *row = cd.trace + (size_t)P.row * cd.rowlen;
@@ -669,6 +683,7 @@ __global__ __launch_bounds__(256) void k_xpass(const SRC chain_src, int s, int w
         if (which & 2) cd.PA[(size_t)bid * ld + i] = aa;
         if (which & 4) cd.PG[(size_t)bid * ld + i] = ag;
     }
+    BNR_TL_OUT(cd, TL_XPASS);
 }
 
 // k_xpass for a lockstep group whose members share the model matrix (chains of one fit: bnr_chain_create_like): ONE workgroup handles a
@@ -972,8 +987,10 @@ __global__ __launch_bounds__(KG * 256, 4 / KG) void k_gram(const SRC chain_src, 
     const int ks = task >> 16;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     int tj = t - ti * (ti + 1) / 2;
+    BNR_TL_IN(cd, TL_GRAM, gslot == 0);
     bnr_gram16_task<KG, false>(bnr_geom_of(cd), Sp, cd.Gpart, t, ti, tj, ks, sred);
     bnr_gram_count(cd, tj);
+    BNR_TL_OUT(cd, TL_GRAM);
 }
 
 // k_gram8: the same Gram, the same task map, the same summation order per element (bitwise the same partial tiles) -- for SIX
@@ -1144,12 +1161,14 @@ __global__ __launch_bounds__(512, 6) void k_gram8(const SRC chain_src, int s, in
     const int ks = task >> 16;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     int tj = t - ti * (ti + 1) / 2;
+    BNR_TL_IN(cd, TL_GRAM, gslot == 0);
 #ifdef BNR_STAMPS
     bnr_gram8_task<false>(bnr_geom_of(cd), Sp, cd.Gpart, t, ti, tj, ks, sred, -1, -1, BNR_G8P_WPC, gslot < 256 ? cd.dbg + 2048 + 4 * gslot : nullptr);
 #else
     bnr_gram8_task<false>(bnr_geom_of(cd), Sp, cd.Gpart, t, ti, tj, ks, sred);
 #endif
     bnr_gram_count(cd, tj);
+    BNR_TL_OUT(cd, TL_GRAM);
 }
 
 // ===================================================================================== the Gram of a BINARY model matrix on the i8 matrix pipe
@@ -1598,7 +1617,7 @@ __device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &
 struct bnr_panelp_lds {
     double sD[BNR_NB * BNR_LP], sB[BNR_NB * BNR_LP];
     double sL[BNR_NB][64];
-#ifdef BNR_STAMPS
+#ifdef BNR_STAMPS_FINE
     unsigned long long st[4][24];          // per wave: [0..11] when a trip's pair of columns was there, [12..19] when an own column was published, [20] polls
 #endif
 };
@@ -1647,7 +1666,7 @@ __device__ __forceinline__ int bnr_sweepN(double (&a)[N], int lane, unsigned pub
             if (BNR_PIPE_TIE && j + 3 < N) asm volatile("ds_write_b64 %1, %2 offset:%3" : "+v"(a[N - 1]) : "v"(pub_addr), "v"(lj), "n"(512 * j) : "memory");
             else asm volatile("ds_write_b64 %1, %2 offset:%3" : "+v"(piv) : "v"(pub_addr), "v"(lj), "n"(512 * j) : "memory");
         }
-#ifdef BNR_STAMPS
+#ifdef BNR_STAMPS_FINE
         if (pst && lane == 0) pst[j] = __builtin_amdgcn_s_memtime();
 #endif
         if (j + 1 < N) a[j + 1] = fma(-lj, t1, a[j + 1]);
@@ -1730,7 +1749,7 @@ __device__ __forceinline__ int bnr_pipe_wave(bnr_panelp_lds &sh, int lane, doubl
         _Pragma("unroll") for (int c = 0; c < 8; ++c) a[c] = fma(-(X1), M[4 + (c >> 1)][c & 1], a[c]);                   \
     } while (0)
     int ntrip = 0, npoll = 0;
-#ifdef BNR_STAMPS
+#ifdef BNR_STAMPS_FINE     // (per-trip and per-pivot stamps perturb what they measure -- s_memtime returns through the LGKM counter --: a build of their own, -DBNR_STAMPS -DBNR_STAMPS_FINE)
 #define BNR_PIPE_TSTAMP() do { if (lane == 0) sh.st[W][ntrip] = __builtin_amdgcn_s_memtime(); ++ntrip; } while (0)
 #else
 #define BNR_PIPE_TSTAMP() do { } while (0)
@@ -1812,12 +1831,12 @@ __device__ __forceinline__ int bnr_pipe_wave(bnr_panelp_lds &sh, int lane, doubl
 #endif
     if (W == 1) BNR_PPH(3);
     if (W == 3) BNR_PPH(6);
-#ifdef BNR_STAMPS
+#ifdef BNR_STAMPS_FINE
     bad |= bnr_sweepN<8, C0, (W < 3 ? 2 : 0)>(a, lane, bnr_lds_addr(&sh.sL[C0][lane]), &sh.st[W][12]);
 #else
     bad |= bnr_sweepN<8, C0, (W < 3 ? 2 : 0)>(a, lane, bnr_lds_addr(&sh.sL[C0][lane]));
 #endif
-#ifdef BNR_STAMPS
+#ifdef BNR_STAMPS_FINE
     if (ph && lane == 0) { sh.st[W][20] = (unsigned long long)npoll; for (int i = 0; i < 24; ++i) ph[1024 + 24 * W + i] = sh.st[W][i]; }
 #endif
     (void)ntrip; (void)npoll;
@@ -1962,6 +1981,9 @@ template <class SRC>
 __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p, int s, int tpw, int spw, int fuse0)
 {
     BNR_CRITICAL_PATH();
+#ifdef BNR_STAMPS
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();       // before anything is read, the kernel's arguments included
+#endif
     if (BNR_EXP_SKIP_CHOL(p)) return;
     const bnr_dev &cd = chain_src.get_x();               // grid = (chains, workgroups): blockIdx.x = chain, blockIdx.y = workgroup
 #if BNR_PANEL_PIPE
@@ -2113,11 +2135,29 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
         const double *bp = E + (size_t)(rho * BNR_NB + nt * 16 + ln) + ld * (size_t)(pc + mt * 16 + lq);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { cD[r] = dp[ld * (size_t)(4 * r)]; cB[r] = bp[ld * (size_t)(4 * r)]; }
+#ifdef BNR_STAMPS           // (wave 0 of panel workgroup 0: entry of the kernel | its loads are back | its MFMAs are done -- words 3800 + 4 p of the debug buffer, tools/stamps_steps.py)
+        if (b == 0 && tid == 0 && p < 24) cd.dbg[3800 + 4 * p] = t_entry;
+        if (p > 0) {
+            const int ln_ = lane & 15, lk_ = lane >> 4;
+            const double *colrows = E + (size_t)(pc + mt * 16) + ld * (size_t)kc, *r1 = E + (size_t)(pc + nt * 16) + ld * (size_t)kc, *r2 = E + (size_t)(rho * BNR_NB + nt * 16) + ld * (size_t)kc;
+            double av[8], b1[8], b2[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) { const size_t o = (size_t)ln_ + ld * (size_t)(4 * ks + lk_); av[ks] = colrows[o]; b1[ks] = r1[o]; b2[ks] = r2[o]; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (b == 0 && tid == 0 && p < 24) cd.dbg[3800 + 4 * p + 1] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) { cD = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[ks], b1[ks], cD, 0, 0, 0); cB = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[ks], b2[ks], cB, 0, 0, 0); }
+            double chk = cD[3] + cB[3];
+            asm volatile("" :: "v"(chk));
+            if (b == 0 && tid == 0 && p < 24) cd.dbg[3800 + 4 * p + 2] = __builtin_amdgcn_s_memtime();
+        }
+#else
         if (p > 0) {
             const double *colrows = E + (size_t)(pc + mt * 16) + ld * (size_t)kc;
             cD = bnr_tile_update(colrows, E + (size_t)(pc + nt * 16) + ld * (size_t)kc, ld, lane, cD);
             cB = bnr_tile_update(colrows, E + (size_t)(rho * BNR_NB + nt * 16) + ld * (size_t)kc, ld, lane, cB);
         }
+#endif
     }
     BNR_STAMP(2);
     // (the factored diagonal block L_pp is needed by nobody after this launch and is NOT written back: every panel workgroup of
@@ -2142,6 +2182,7 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
     BNR_STAMP(4);
 #ifdef BNR_STAMPS
     if (lane == 0) atomicMax((unsigned long long *)&cd.dbg[p * 8 + 5], (unsigned long long)__builtin_amdgcn_s_memrealtime());      // (every wave: with the pipelined sweep wave 3 is the last one)
+    if (b == 0 && tid == 192 && p < 48) { cd.dbg[3900 + 2 * p] = __builtin_amdgcn_s_memrealtime(); cd.dbg[3901 + 2 * p] = __builtin_amdgcn_s_memtime(); }      // the LAST wave of panel workgroup 0 on both clocks (tools/stamps_steps.py: which clock do the panel steps run at?)
 #endif
 }
 
@@ -2432,6 +2473,7 @@ __global__ __launch_bounds__(256) void k_rhs(const SRC chain_src, int s)
     const int n = cd.n;
     const size_t ld = cd.n_pad;
     const int il = threadIdx.x & 63, g = threadIdx.x >> 6, i = blockIdx.x * 64 + il;
+    BNR_TL_IN(cd, TL_RHS, blockIdx.x == 0);
     double xw = 0.0, xs = 0.0;
     const int nb = cd.nblk_x;
     // (the partials of a row are added in ascending block order whatever the batch size: 16 + 16 loads in flight per round trip instead of 8 + 8 -- the kernel is
@@ -2462,6 +2504,7 @@ __global__ __launch_bounds__(256) void k_rhs(const SRC chain_src, int s)
         cd.xw[i] = xw; cd.a3[i] = xs;          // a3 buffer keeps X sz (without z2)
         cd.bw[i] = bb;                         // b, kept for the bookkeeping after the solve
     }
+    BNR_TL_OUT(cd, TL_RHS);
 }
 // Solve with Y = L^-T (rows [n_pad, 2 n_pad) of E, upper triangular, column-major): a4 = Y (Y' b).
 // The factorization itself never sees b, so the scalar branch of the sweep (tail, node, X W pass, k_rhs) only has to be
@@ -2474,6 +2517,7 @@ __global__ __launch_bounds__(256) void k_solve_w(const SRC chain_src)
     const bnr_dev &cd = chain_src.get();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, np = cd.n_pad;
     const int c = blockIdx.x * 4 + wave;
+    BNR_TL_IN(cd, TL_SOLVE_W, blockIdx.x == 0);
     const size_t ld = bnr_ldE(np);
     const double *col = cd.E + (size_t)np + ld * (size_t)c;
     const int rend = (c / BNR_NB + 1) * BNR_NB;            // entries below the diagonal block are exactly zero
@@ -2481,6 +2525,7 @@ __global__ __launch_bounds__(256) void k_solve_w(const SRC chain_src)
     for (int r = lane; r < rend; r += 64) acc = fma(col[r], cd.bw[r], acc);
     acc = wave_sum(acc);
     if (lane == 0) cd.wv[c] = acc;
+    BNR_TL_OUT(cd, TL_SOLVE_W);
 }
 // k_solve_a4: a4_r = sum_{c >= block(r)} Y[r,c] w_c, then X gamma_new = X W + tau X sz + tau G a4, G a4 = b - a4
 // (no third pass over X).  grid = nbk blocks (one per block row), 1024 threads = 32 rows x 32 column groups.
@@ -2495,6 +2540,7 @@ __global__ __launch_bounds__(1024) void k_solve_a4(const SRC chain_src)
     const size_t ld = bnr_ldE(np);
     const int rb = blockIdx.x, rl = tid & 31, cg = tid >> 5;
     const int cstart = rb * BNR_NB;
+    BNR_TL_IN(cd, TL_SOLVE_A4, rb == 0);
     for (int c = cstart + tid; c < np; c += 1024) swv[c] = cd.wv[c];
     __syncthreads();
     const double *yrow = cd.E + (size_t)(np + rb * BNR_NB + rl);
@@ -2513,6 +2559,7 @@ __global__ __launch_bounds__(1024) void k_solve_a4(const SRC chain_src)
         cd.a4[r] = a4;
         cd.xg[r] = (r < cd.n) ? (cd.xw[r] + tau * cd.a3[r] + tau * (bb - a4)) : 0.0;
     }
+    BNR_TL_OUT(cd, TL_SOLVE_A4);
 }
 
 // ===================================================================================== k_backproj
@@ -2550,6 +2597,7 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
 #ifdef BNR_STAMPS
     if (tid == 0 && bid < 1800) cd.dbg[400 + 2 * bid] = __builtin_amdgcn_s_memrealtime();
 #endif
+    BNR_TL_IN(cd, (flags & 3) ? TL_BACKPROJ : TL_PSUM, bid == 0);
     // u[r,l] u[r,k] of this block's edges for the Lambda log-likelihoods at the end: requested now, so that the dependent
     // global loads (edge -> nodes -> u) are in flight behind the dot products instead of in front of the final sums
     __shared__ double sdr[BNR_RMAX * 33];
@@ -2705,6 +2753,7 @@ __global__ __launch_bounds__(256) void k_backproj(const SRC chain_src, int s, in
     BNR_BSTAMP(3);
 #ifdef BNR_STAMPS
     if (lane == 0 && bid < 1800) cd.dbg[401 + 2 * bid] = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) atomicMax((unsigned long long *)&cd.dbg[4000 + 4 * ((flags & 3) ? TL_BACKPROJ : TL_PSUM) + 2], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
     if (cap && lane < 32) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
 }
@@ -2754,7 +2803,8 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
     BNR_TSTAMP(0);
     if (gridDim.x == 2) {
         // a sweep's launch: workgroup 1 of the chain does Delta, M, inv(M) (what needs only k_node's output), workgroup 0 the rest, side by side
-        if (blockIdx.x == 1) { if (mask & BNR_TAIL_EARLY) bnr_tail_a(cd, P, mask, su_lds, tid, (mask & 128) != 0); return; }
+        if (blockIdx.x == 1) { BNR_TL_IN(cd, TL_TAIL_A, true); if (mask & BNR_TAIL_EARLY) bnr_tail_a(cd, P, mask, su_lds, tid, (mask & 128) != 0); BNR_TL_OUT(cd, TL_TAIL_A); return; }
+        BNR_TL_IN(cd, TL_TAIL, true);
         mask &= ~BNR_TAIL_EARLY;
     } else if (mask & BNR_TAIL_EARLY) {            // one workgroup for everything (hooks, a loaded or initialised row): the early part first
         bnr_tail_a(cd, P, mask, su_lds + (ULDS ? (size_t)R * V : 0), tid);
@@ -2942,6 +2992,7 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
         }
     }
     BNR_TSTAMP(6);
+    if (gridDim.x == 2) BNR_TL_OUT(cd, TL_TAIL);
     if (cap) atomicAdd((unsigned long long *)&cd.counters[2], 1ull);
 #ifdef BNR_EXP_PAD
     // timing experiment only (never in the shipped build): the kernel ends xg_src >> 8 microseconds later, to move the start of what follows it on the scalar branch

@@ -22,6 +22,9 @@ __global__ __launch_bounds__(256, 1) void k_lab(const double *D, const double *B
     __shared__ unsigned long long s_end, s_endw[4];
     for (int rep = 0; rep < reps; ++rep) {
         if (tid == 0) s_end = 0;
+#ifdef BNR_LAB_COLD_ICACHE       // every repetition starts with an empty instruction cache, as every launch of the product kernel does (the code of a panel step runs once per launch)
+        asm volatile("s_icache_inv\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0" ::: "memory");
+#endif
         __syncthreads();
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #if BNR_PANEL_PIPE
@@ -63,6 +66,17 @@ int main()
     hipMemcpy(O.data(), dO, 8 * 1024, hipMemcpyDeviceToHost); hipMemcpy(hC, dC, 128, hipMemcpyDeviceToHost);
     double err = 0; for (int i = 0; i < 1024; ++i) err = std::fmax(err, std::fabs(O[i] - X[i]) / (1e-12 + std::fabs(X[i])));
     printf("panel sweep: %llu cycles on average from entry to the last wave's end (worst %llu) over 200 sweeps; waves 0..3 end at %llu %llu %llu %llu; max relative error against the host %.2e; bad pivot flag %llu\n", hC[0], hC[1], hC[4], hC[5], hC[6], hC[7], err, hC[3]);
+    // the same sweep ONCE per launch (as the product runs it: a panel step's code runs once per launch on a CU that was idle before), 1 and 48 workgroups, 40 launches each
+    for (int wgs : {1, 48}) {
+        unsigned long long acc[16] = {0};
+        for (int it = 0; it < 40; ++it) {
+            hipLaunchKernelGGL(k_lab, dim3(wgs), dim3(256), 0, 0, dD, dB, dO, dC, 1); hipDeviceSynchronize();
+            unsigned long long h2[16]; hipMemcpy(h2, dC, 128, hipMemcpyDeviceToHost);
+            if (it >= 8) for (int i = 0; i < 16; ++i) acc[i] += h2[i];
+        }
+        printf("one sweep per launch, %2d workgroup(s) (the last one to write its stamps is reported): %llu cycles; waves 0..3 end at %llu %llu %llu %llu; own pivots %llu..%llu  %llu..%llu  %llu..%llu  %llu..%llu\n", wgs, acc[0] / 32, acc[4] / 32, acc[5] / 32,
+               acc[6] / 32, acc[7] / 32, acc[8] / 32, acc[9] / 32, acc[10] / 32, acc[11] / 32, acc[12] / 32, acc[13] / 32, acc[14] / 32, acc[15] / 32);
+    }
 #ifdef BNR_LAB_STAMPS
     printf("  own pivots of waves 0..3 start..end: %llu..%llu  %llu..%llu  %llu..%llu  %llu..%llu\n", hC[8], hC[9], hC[10], hC[11], hC[12], hC[13], hC[14], hC[15]);
 #endif
