@@ -1405,6 +1405,9 @@ __device__ __forceinline__ double bnr_readlane(double v, int srclane)
     return __hiloint2double(hi, lo);
 }
 #define BNR_LP (BNR_NB + 1)
+#ifndef BNR_PANEL_COOP_FETCH
+#define BNR_PANEL_COOP_FETCH 1   // 1: a panel workgroup fetches the two blocks of panel p - 1 once, through LDS (round 6); 0: every wave its own fragments from memory
+#endif
 #ifndef BNR_PANEL_PIPE
 #define BNR_PANEL_PIPE 1      // 1: the panel sweep as a pipeline of the workgroup's four waves (round 6, bnr_panel_sweep_pipe); 0: one sweeping wave (rounds 1-5)
 #endif
@@ -1614,7 +1617,7 @@ __device__ __forceinline__ int bnr_panel_sweep(bnr_panel_lds &sh, const bnr_d4 &
 #define BNR_PIPE_HEAVY 0    // 1: a starved wave polls with all ten reads instead of one (one chain 169.5 against 168.0 us per sweep)
 #endif
 #define BNR_PIPE_SENT_HI 0x7FF8DEAD
-struct bnr_panelp_lds {
+struct alignas(16) bnr_panelp_lds {
     double sD[BNR_NB * BNR_LP], sB[BNR_NB * BNR_LP];
     double sL[BNR_NB][64];
 #ifdef BNR_STAMPS_FINE
@@ -1991,6 +1994,10 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
 #else
     __shared__ bnr_panel_lds sh;
 #endif
+#if BNR_PANEL_COOP_FETCH
+    static_assert(BNR_PANEL_PIPE && sizeof(sh.sL) == 2 * BNR_NB * BNR_NB * sizeof(double), "the two fetched blocks of panel p - 1 live where the sweep's published columns will be");
+    double (*sPO)[BNR_NB * BNR_NB] = (double (*)[BNR_NB * BNR_NB])&sh.sL[0][0];   // (no LDS of their own: the update workgroups of the launch carry the same static allocation)
+#endif
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nbk = cd.n_pad / BNR_NB;
     const size_t ld = bnr_ldE(cd.n_pad);
     const int npanel = bnr_chol_npanel(nbk, p);
@@ -2137,19 +2144,39 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(const SRC chain_src, int p
         for (int r = 0; r < 4; ++r) { cD[r] = dp[ld * (size_t)(4 * r)]; cB[r] = bp[ld * (size_t)(4 * r)]; }
 #ifdef BNR_STAMPS           // (wave 0 of panel workgroup 0: entry of the kernel | its loads are back | its MFMAs are done -- words 3800 + 4 p of the debug buffer, tools/stamps_steps.py)
         if (b == 0 && tid == 0 && p < 24) cd.dbg[3800 + 4 * p] = t_entry;
+#endif
+#if BNR_PANEL_COOP_FETCH
         if (p > 0) {
-            const int ln_ = lane & 15, lk_ = lane >> 4;
-            const double *colrows = E + (size_t)(pc + mt * 16) + ld * (size_t)kc, *r1 = E + (size_t)(pc + nt * 16) + ld * (size_t)kc, *r2 = E + (size_t)(rho * BNR_NB + nt * 16) + ld * (size_t)kc;
+            // The K = 32 update of both blocks with panel p - 1: the two 32 x 32 blocks of that panel it needs -- P = L[p, p-1] and O = L[own, p-1] -- are fetched ONCE per
+            // workgroup, 16 bytes per lane and whole columns per quarter wave, into LDS; the MFMA fragments come from there.  (Fragments straight from memory: every wave
+            // fetched its three sets itself, 24 eight-byte loads per lane, each a quarter line of four columns -- 64 KB through the CU's 64 B/clk vector-memory path where
+            // 32 KB are distinct, 3 100 cycles until the loads were back; profiles/round6_experiments_notes.txt J.)  Same products in the same order: bitwise the same blocks.
+            // Image: column c at 32 c doubles, the two 16-row halves of the odd columns swapped: a fragment read (16 rows x columns 4 ks + (0, 1) per half wave) covers all banks once.
+            const int fc = tid >> 4, fr = (tid & 15) * 2;                       // this thread: rows fr, fr + 1 of the columns fc and fc + 16
+            const double *gP = E + (size_t)(pc + fr) + ld * (size_t)(kc + fc), *gO = E + (size_t)(rho * BNR_NB + fr) + ld * (size_t)(kc + fc);
+            const bnr_d2 p0 = *(const bnr_d2 *)gP, p1 = *(const bnr_d2 *)(gP + ld * 16), o0 = *(const bnr_d2 *)gO, o1 = *(const bnr_d2 *)(gO + ld * 16);
+            const int wo = (fr ^ ((fc & 1) << 4)) + 32 * fc;
+            *(bnr_d2 *)&sPO[0][wo] = p0; *(bnr_d2 *)&sPO[0][wo + 512] = p1;
+            *(bnr_d2 *)&sPO[1][wo] = o0; *(bnr_d2 *)&sPO[1][wo + 512] = o1;
+            __syncthreads();
+#ifdef BNR_STAMPS
+            if (b == 0 && tid == 0 && p < 24) cd.dbg[3800 + 4 * p + 1] = __builtin_amdgcn_s_memtime();
+#endif
+            const int lk = lane >> 4;
             double av[8], b1[8], b2[8];
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) { const size_t o = (size_t)ln_ + ld * (size_t)(4 * ks + lk_); av[ks] = colrows[o]; b1[ks] = r1[o]; b2[ks] = r2[o]; }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (b == 0 && tid == 0 && p < 24) cd.dbg[3800 + 4 * p + 1] = __builtin_amdgcn_s_memtime();
+            for (int ks = 0; ks < 8; ++ks) {
+                const int c = 4 * ks + lk, sw = (c & 1) << 4;
+                av[ks] = sPO[0][((mt * 16 + ln) ^ sw) + 32 * c]; b1[ks] = sPO[0][((nt * 16 + ln) ^ sw) + 32 * c]; b2[ks] = sPO[1][((nt * 16 + ln) ^ sw) + 32 * c];
+            }
+            __syncthreads();                    // every wave has its fragments in registers: the sweep may write its "not there yet" marks over the two blocks
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) { cD = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[ks], b1[ks], cD, 0, 0, 0); cB = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[ks], b2[ks], cB, 0, 0, 0); }
-            double chk = cD[3] + cB[3];
-            asm volatile("" :: "v"(chk));
-            if (b == 0 && tid == 0 && p < 24) cd.dbg[3800 + 4 * p + 2] = __builtin_amdgcn_s_memtime();
+            for (int ks = 0; ks < 8; ++ks) cD = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[ks], b1[ks], cD, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) cB = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[ks], b2[ks], cB, 0, 0, 0);
+#ifdef BNR_STAMPS
+            { double chk = cD[3] + cB[3]; asm volatile("" :: "v"(chk)); if (b == 0 && tid == 0 && p < 24) cd.dbg[3800 + 4 * p + 2] = __builtin_amdgcn_s_memtime(); }
+#endif
         }
 #else
         if (p > 0) {
