@@ -14,7 +14,7 @@ r = bnr_amd.Group(chains) if nb > 1 else chains[0]
 for kv in opts:
     k, v = kv.split("="); r.set_option(k, int(v))
 r.run(2, 40, 40)
-nbk = (n + 31) // 32
+nbk = ((n + 63) // 64 * 64) // 32          # n_pad is a multiple of the Gram tile (64)
 d = chains[0].debug_read(nbk * 8).reshape(nbk, 8).astype(np.int64)
 print("n=%d V=%d R=%d, %d chain(s): cycles of panel workgroup 0 of chain 1 [fetch + pending update | sweep | store], wave 0's total; the workgroup's last wave on the shader clock and on the 100 MHz clock" % (n, V, R, nb))
 e = chains[0].debug_read(4096)[3900:3900 + 2 * nbk].reshape(nbk, 2).astype(np.int64)       # the last wave's end on both clocks

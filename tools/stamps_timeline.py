@@ -18,7 +18,7 @@ for kv in opts:
 r.run(2, 48, 48)
 KINDS = ["gram", "solve_w", "solve_a4", "backproj", "psum", "tail", "tail_a", "node", "xpass", "rhs", "sdigits"]
 d = np.stack([ch.debug_read(4096).astype(np.int64) for ch in chains])       # chain, word
-nbk = ((n + 31) // 32 * 32) // 32
+nbk = ((n + 63) // 64 * 64) // 32          # n_pad is a multiple of the Gram tile (64)
 rows = []
 for k, name in enumerate(KINDS):
     w = d[:, 4000 + 4 * k: 4000 + 4 * k + 3]
