@@ -1405,6 +1405,9 @@ __device__ __forceinline__ double bnr_readlane(double v, int srclane)
     return __hiloint2double(hi, lo);
 }
 #define BNR_LP (BNR_NB + 1)
+#ifndef BNR_PIPE_DPP
+#define BNR_PIPE_DPP 1       // 1: the consuming waves of the panel pipeline take a column's multipliers by DPP row broadcast out of ONE LDS read (round 6, second half); 0: lane-uniform 16-byte LDS reads
+#endif
 #ifndef BNR_PANEL_COOP_FETCH
 #define BNR_PANEL_COOP_FETCH 1   // 1: a panel workgroup fetches the two blocks of panel p - 1 once, through LDS (round 6); 0: every wave its own fragments from memory
 #endif
@@ -1626,8 +1629,10 @@ struct alignas(16) bnr_panelp_lds {
 };
 __device__ __forceinline__ unsigned bnr_lds_addr(const void *p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void *)p; }
 // sweep of N panel columns held one row per lane: column j's pivot sits in lane COFF + j.  PUB: 0 nothing, 2 every finished column goes to pub + 512 j bytes (LDS, lane = row)
-template <int N, int COFF, int PUB>
-__device__ __forceinline__ int bnr_sweepN(double (&a)[N], int lane, unsigned pub_addr, unsigned long long *pst = nullptr)
+struct bnr_no_hook { __device__ __forceinline__ void operator()() const {} };
+// (hook: called once, behind the issue of the first pivot's v_rsq_f64 -- multiply-adds of the wave's columns 2 .. N - 1 that are still pending run in that shadow)
+template <int N, int COFF, int PUB, class HOOK = bnr_no_hook>
+__device__ __forceinline__ int bnr_sweepN(double (&a)[N], int lane, unsigned pub_addr, unsigned long long *pst = nullptr, HOOK hook = HOOK())
 {
     int bad = 0;
     double lprev = 0.0;
@@ -1640,6 +1645,7 @@ __device__ __forceinline__ int bnr_sweepN(double (&a)[N], int lane, unsigned pub
         if (j + 2 < N) s3 = bnr_readlane(a[j], COFF + j + 2);
         if (!(piv > 0.0)) bad = 1;
         double y = __builtin_amdgcn_rsq(piv);
+        if (j == 0) hook();
 #if BNR_PIPE_LATEPUB
         // column j - 1 goes to LDS here, right behind the issue of this pivot's v_rsq_f64 and named as its consumer: the store's issue slot sits inside the rsq's latency
         // instead of between "next pivot known" and "its rsq issued" (measured: a publishing wave walks its pivots at ~155 cycles each, one that publishes nothing at ~118)
@@ -1708,6 +1714,7 @@ __device__ __forceinline__ int bnr_pipe_wave(bnr_panelp_lds &sh, int lane, doubl
     unsigned vcol = bnr_lds_addr(&sh.sL[0][lane]), vmul = bnr_lds_addr(&sh.sL[0][C0]);
     double c0 = 0.0, c1 = 0.0, n0 = 0.0, n1 = 0.0;
     bnr_d2 m[8], mn[8];
+    (void)vmul; (void)c0; (void)c1; (void)n0; (void)n1; (void)m; (void)mn;          // (the lane-uniform path's registers; unused with BNR_PIPE_DPP)
     // (OFF: byte offset of the column pair relative to the running addresses vcol / vmul)
 #define BNR_PIPE_READ10(X0, X1, M, OFF)                                                                                                                      \
     asm volatile("ds_read_b64 %0, %10 offset:%12\n\tds_read_b64 %1, %10 offset:%13\n\t"                                                                      \
@@ -1757,7 +1764,68 @@ __device__ __forceinline__ int bnr_pipe_wave(bnr_panelp_lds &sh, int lane, doubl
 #else
 #define BNR_PIPE_TSTAMP() do { } while (0)
 #endif
-#if BNR_PIPE_FASTHAND
+#if BNR_PIPE_DPP
+    // The eight multipliers of a column -- its rows C0 .. C0 + 7 -- reach the lanes by DPP, not by lane-uniform LDS reads: one ds_read_b64 per column puts them into lanes
+    // 0 .. 7 of every row of 16 lanes (lane q of a row reads row C0 + (q & 7): eight distinct addresses in 64 bytes, conflict-free), and the multiply-add takes its multiplier
+    // as "lane n of my row" (v_fmac_f64 with the DPP control row_newbcast:n, the one DPP mode of 64-bit operands): per column pair four ds_read_b64 = 2 KiB through the LDS
+    // pipe instead of two ds_read_b64 + eight lane-uniform ds_read_b128 = 9 KiB (a lane-uniform read costs its full 1 KiB pass), and 4 VGPRs of multipliers instead of 32.
+    // Same products (-m x = -x m), same fused multiply-adds in the same order per element: bitwise the values of the other path.
+    unsigned vc = vcol, vm = bnr_lds_addr(&sh.sL[0][C0 + (lane & 7)]);
+    double x0 = 0.0, x1 = 0.0, m0 = 0.0, m1 = 0.0, y0 = 0.0, y1 = 0.0, q0 = 0.0, q1 = 0.0;
+#define BNR_DPP_READ4(X0, X1, M0, M1, OFF)                                                                                                                   \
+    do { asm volatile("ds_read_b64 %0, %4 offset:%6\n\tds_read_b64 %1, %4 offset:%7\n\tds_read_b64 %2, %5 offset:%6\n\tds_read_b64 %3, %5 offset:%7"          \
+                 : "=&v"(X0), "=&v"(X1), "=&v"(M0), "=&v"(M1) : "v"(vc), "v"(vm), "n"(OFF), "n"((OFF) + 512) : "memory");                                    \
+         asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])); } while (0)
+#define BNR_DPP_WAIT4(X0, X1, M0, M1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X0), "+v"(X1), "+v"(M0), "+v"(M1), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) :: "memory")
+    // (not volatile: the scheduler places them by their operands -- behind the wait that names the registers, in front of whatever reads the column)
+#define BNR_DPP_FMA(C, MM, X) asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a[C]) : "v"(MM), "v"(X), "n"(C))
+#define BNR_DPP_APPLY(CFROM, X0, X1, M0, M1)                                                                                                                 \
+    do { _Pragma("unroll") for (int c_ = (CFROM); c_ < 8; ++c_) {                                                                                            \
+             switch (c_) {                                                                                                                                   \
+             case 0: BNR_DPP_FMA(0, M0, X0); BNR_DPP_FMA(0, M1, X1); break; case 1: BNR_DPP_FMA(1, M0, X0); BNR_DPP_FMA(1, M1, X1); break;                     \
+             case 2: BNR_DPP_FMA(2, M0, X0); BNR_DPP_FMA(2, M1, X1); break; case 3: BNR_DPP_FMA(3, M0, X0); BNR_DPP_FMA(3, M1, X1); break;                     \
+             case 4: BNR_DPP_FMA(4, M0, X0); BNR_DPP_FMA(4, M1, X1); break; case 5: BNR_DPP_FMA(5, M0, X0); BNR_DPP_FMA(5, M1, X1); break;                     \
+             case 6: BNR_DPP_FMA(6, M0, X0); BNR_DPP_FMA(6, M1, X1); break; default: BNR_DPP_FMA(7, M0, X0); BNR_DPP_FMA(7, M1, X1); break; } } } while (0)
+    // one trip: the pair at OFF is in flight into (X0, X1, M0, M1); wait, read again until it is there, start the next pair's reads, apply
+#define BNR_DPP_TRIP(X0, X1, M0, M1, OFF, Y0, Y1, Q0, Q1)                                                                \
+    do {                                                                                                                \
+        BNR_DPP_WAIT4(X0, X1, M0, M1);                                                                                  \
+        if (!BNR_PIPE_HERE(X0, X1)) {                                                                                   \
+            int spins = 0;                                                                                              \
+            do {                                                                                                        \
+                if (++spins > BNR_PIPE_SPINS) { bad = 1; break; }                                                       \
+                BNR_DPP_READ4(X0, X1, M0, M1, OFF);                                                                     \
+                BNR_DPP_WAIT4(X0, X1, M0, M1);                                                                          \
+            } while (!BNR_PIPE_HERE(X0, X1));                                                                           \
+        }                                                                                                               \
+        BNR_DPP_READ4(Y0, Y1, Q0, Q1, (OFF) + 1024);                                                                    \
+        BNR_DPP_APPLY(0, X0, X1, M0, M1);                                                                               \
+    } while (0)
+    if (W > 0) {
+        // C0 / 2 trips (4, 8, 12): all but the last in pairs through the rolled loop + one more; the LAST pair is the hand-over of the pivot chain to this wave: the moment it
+        // is there the own columns 0 and 1 are brought up to date and the pivot chain starts; the other twelve multiply-adds run in the shadow of the first pivot's v_rsq_f64
+        constexpr int NT = C0 / 2;
+        BNR_DPP_READ4(x0, x1, m0, m1, 0);
+#pragma unroll 1
+        for (int t = 0; t + 2 < NT; t += 2) {
+            BNR_DPP_TRIP(x0, x1, m0, m1, 0, y0, y1, q0, q1);
+            BNR_DPP_TRIP(y0, y1, q0, q1, 1024, x0, x1, m0, m1);
+            vc += 2048; vm += 2048;
+        }
+        BNR_DPP_TRIP(x0, x1, m0, m1, 0, y0, y1, q0, q1);                  // trip NT - 2; the hand-over pair's reads go out under its multiply-adds
+        BNR_DPP_WAIT4(y0, y1, q0, q1);
+        if (!BNR_PIPE_HERE(y0, y1)) {
+            int spins = 0;
+            do {
+                if (++spins > BNR_PIPE_SPINS) { bad = 1; break; }
+                BNR_DPP_READ4(y0, y1, q0, q1, 1024);
+                BNR_DPP_WAIT4(y0, y1, q0, q1);
+            } while (!BNR_PIPE_HERE(y0, y1));
+        }
+        BNR_DPP_FMA(0, q0, y0); BNR_DPP_FMA(0, q1, y1); BNR_DPP_FMA(1, q0, y0); BNR_DPP_FMA(1, q1, y1);
+    }
+#define BNR_DPP_PENDING() do { if (W > 0) BNR_DPP_APPLY(2, y0, y1, q0, q1); } while (0)
+#elif BNR_PIPE_FASTHAND
     // The LAST pair of columns is the hand-over of the pivot chain to this wave: what starts this wave's first pivot is its own columns 0 and 1 only.  So the last pair is
     // not fetched like the others (one poll round trip for "is it there", then a second one for the ten reads): the poll itself reads this lane's row of both columns and the
     // multiplier pair of the own columns 0, 1 of each (four reads), the moment they are there columns 0, 1 are brought up to date and the pivot chain can start; the other six
@@ -1834,7 +1902,9 @@ __device__ __forceinline__ int bnr_pipe_wave(bnr_panelp_lds &sh, int lane, doubl
 #endif
     if (W == 1) BNR_PPH(3);
     if (W == 3) BNR_PPH(6);
-#ifdef BNR_STAMPS_FINE
+#if BNR_PIPE_DPP
+    bad |= bnr_sweepN<8, C0, (W < 3 ? 2 : 0)>(a, lane, bnr_lds_addr(&sh.sL[C0][lane]), nullptr, [&]() { BNR_DPP_PENDING(); });
+#elif defined(BNR_STAMPS_FINE)
     bad |= bnr_sweepN<8, C0, (W < 3 ? 2 : 0)>(a, lane, bnr_lds_addr(&sh.sL[C0][lane]), &sh.st[W][12]);
 #else
     bad |= bnr_sweepN<8, C0, (W < 3 ? 2 : 0)>(a, lane, bnr_lds_addr(&sh.sL[C0][lane]));
