@@ -503,7 +503,10 @@ __device__ inline void wave_tri_inverse(const double *A, double *T, int R, int l
 //   lds: 4 R^2 + 8 doubles.
 #define BNR_TAIL_EARLY (2 | 4 | 256)
 __host__ __device__ inline size_t bnr_tail_a_lds_doubles(int R) { return (size_t)4 * R * R + 8; }
-__device__ __forceinline__ void bnr_tail_a(const bnr_dev &cd, const bnr_plan_entry P, int mask, double *lds, int tid, bool mirror = false)
+// ustage (round 6, second half): R V doubles of LDS, or nullptr.  Psi = I + sum_v u_v u_v' is a sum in the order of v per entry; with u read from the table row the loop
+// is V / 4 dependent round trips to memory (four nodes' loads in flight): 25 of them at V = 100 were 15 of this function's 18 us.  Staged once -- one round trip -- the same
+// terms are added in the same order out of LDS.
+__device__ __forceinline__ void bnr_tail_a(const bnr_dev &cd, const bnr_plan_entry P, int mask, double *lds, int tid, bool mirror = false, double *ustage = nullptr)
 {
     // mirror: this is workgroup 1 of a sweep's two-workgroup launch and the row is being copied to the head of the table by workgroup 0 at the same time (purge ring,
     // gibbs.jl:857-860): workgroup 0 leaves Delta and M out of its copy, they are written to the copies from here
@@ -515,6 +518,7 @@ __device__ __forceinline__ void bnr_tail_a(const bnr_dev &cd, const bnr_plan_ent
     double *row = bnr_sgpr_global(cd.trace + (size_t)P.row * cd.rowlen);
     const double *su_row = row + cd.o_u;
     int cap = 0;
+    if (ustage && (mask & 4)) { for (int i = tid; i < R * V; i += (int)blockDim.x) ustage[i] = su_row[i]; }
     // sum xi, #nonzero xi (sums of zeros and ones: exact whatever the order)
     if (act && (mask & (2 | 4))) {
         double sxi = 0.0, snz = 0.0;
@@ -523,6 +527,24 @@ __device__ __forceinline__ void bnr_tail_a(const bnr_dev &cd, const bnr_plan_ent
         if (lane == 0) { sredA[wave] = sxi; sredA[4 + wave] = snz; }
     }
     // Psi = I + sum_v u_v u_v' (gibbs.jl:516-525), sequential over v per entry (the reference's order); u from the table row (k_node has just written it)
+    if (ustage && (mask & 4)) {
+        __syncthreads();
+        if (act) {
+            for (int idx = tid; idx < RR; idx += 256) {
+                const int a = idx % R, b = idx / R;
+                double sacc = (a == b) ? 1.0 : 0.0;
+                int v = 0;
+                for (; v + 3 < V; v += 4) {
+                    const double a0 = ustage[a + R * v], b0 = ustage[b + R * v], a1 = ustage[a + R * (v + 1)], b1 = ustage[b + R * (v + 1)];
+                    const double a2 = ustage[a + R * (v + 2)], b2 = ustage[b + R * (v + 2)], a3 = ustage[a + R * (v + 3)], b3 = ustage[b + R * (v + 3)];
+                    sacc += a0 * b0; sacc += a1 * b1; sacc += a2 * b2; sacc += a3 * b3;
+                }
+                for (; v < V; ++v) sacc += ustage[a + R * v] * ustage[b + R * v];
+                sPsi[idx] = sacc;
+                sA[idx] = sacc;
+            }
+        }
+    } else
     if (act && (mask & 4)) {
         for (int idx = tid; idx < RR; idx += 256) {
             const int a = idx % R, b = idx / R;
@@ -2900,11 +2922,11 @@ __global__ __launch_bounds__(BNR_TAIL_THREADS) void k_tail(const SRC chain_src, 
     BNR_TSTAMP(0);
     if (gridDim.x == 2) {
         // a sweep's launch: workgroup 1 of the chain does Delta, M, inv(M) (what needs only k_node's output), workgroup 0 the rest, side by side
-        if (blockIdx.x == 1) { BNR_TL_IN(cd, TL_TAIL_A, true); if (mask & BNR_TAIL_EARLY) bnr_tail_a(cd, P, mask, su_lds, tid, (mask & 128) != 0); BNR_TL_OUT(cd, TL_TAIL_A); return; }
+        if (blockIdx.x == 1) { BNR_TL_IN(cd, TL_TAIL_A, true); if (mask & BNR_TAIL_EARLY) bnr_tail_a(cd, P, mask, su_lds, tid, (mask & 128) != 0, ULDS ? su_lds + bnr_tail_a_lds_doubles(R) : nullptr); BNR_TL_OUT(cd, TL_TAIL_A); return; }
         BNR_TL_IN(cd, TL_TAIL, true);
         mask &= ~BNR_TAIL_EARLY;
     } else if (mask & BNR_TAIL_EARLY) {            // one workgroup for everything (hooks, a loaded or initialised row): the early part first
-        bnr_tail_a(cd, P, mask, su_lds + (ULDS ? (size_t)R * V : 0), tid);
+        bnr_tail_a(cd, P, mask, su_lds + (ULDS ? (size_t)R * V : 0), tid, false, ULDS ? su_lds : nullptr);     // (u staged where the late part will stage it again)
         if (!(mask & ~BNR_TAIL_EARLY)) return;
         __syncthreads();
     }
